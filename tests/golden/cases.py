@@ -1,0 +1,133 @@
+"""Golden-vector case definitions shared by the generator (make_golden.py, runs only where
+/root/reference exists) and by the parity tests (run anywhere).
+
+Everything here is numpy-only and deterministic: inputs and weights come from
+``numpy.random.RandomState`` (MT19937 — stable across numpy versions), never from torch's RNG,
+so the GPU box can rebuild the *inputs* of every golden case without the reference and without
+shipping multi-megabyte state_dicts.  Only the reference's *outputs* are stored in the .npz files.
+
+Case vocabulary follows SURVEY.md §8(c): G1 knot tables, G2 phi, G3 psi, G4 feature column order,
+G5 y/loss/grads, G6 one optimiser step.
+"""
+import math
+import numpy as np
+
+KNOT_SIDES = [3, 5, 9, 11, 32, 64, 72, 100]          # G1
+TEMPORAL_NS = [1, 5, 10, 15, 45]                      # G3 / A4
+
+# name -> model config + batch.  `mlp_idx` bookkeeping is derived in state_layout().
+MODEL_CASES = {
+    # reference test-suite config (direct-cdist regime: B<=25 and K<=25)
+    "tiny9": dict(p=0, k_spatial_centers=[9], k_temporal_centers=[5], hidden_dims=[32, 16],
+                  layernorm=False, basis="wendland", output_dim=1, B=4, seed=11),
+    "tiny9_ln_p3": dict(p=3, k_spatial_centers=[9], k_temporal_centers=[5], hidden_dims=[32, 16],
+                        layernorm=True, basis="wendland", output_dim=1, B=7, seed=12),
+    # shipped default sizes (K_s=227, K_t=70, D=297, 176 385 params)
+    "default227": dict(p=0, k_spatial_centers=[25, 81, 121], k_temporal_centers=[10, 15, 45],
+                       hidden_dims=[256, 256, 128], layernorm=True, basis="wendland",
+                       output_dim=1, B=193, seed=13),
+    "default227_noln": dict(p=0, k_spatial_centers=[25, 81, 121], k_temporal_centers=[10, 15, 45],
+                            hidden_dims=[256, 256, 128], layernorm=False, basis="wendland",
+                            output_dim=1, B=130, seed=14),
+    "default227_gauss": dict(p=2, k_spatial_centers=[25, 81, 121], k_temporal_centers=[10, 15, 45],
+                             hidden_dims=[256, 256, 128], layernorm=True, basis="gaussian",
+                             output_dim=1, B=65, seed=15),
+    "default227_tri": dict(p=0, k_spatial_centers=[25, 81, 121], k_temporal_centers=[10, 15, 45],
+                           hidden_dims=[256, 256, 128], layernorm=True, basis="triangular",
+                           output_dim=1, B=65, seed=16),
+    # BASELINE config C2/C3 model (K_s=10 304, D=10 374, 2 756 097 params), ragged batch
+    "c2_b257": dict(p=0, k_spatial_centers=[1024, 4096, 5184], k_temporal_centers=[10, 15, 45],
+                    hidden_dims=[256, 256, 128], layernorm=True, basis="wendland",
+                    output_dim=1, B=257, seed=17),
+    "c2_b257_noln": dict(p=0, k_spatial_centers=[1024, 4096, 5184], k_temporal_centers=[10, 15, 45],
+                         hidden_dims=[256, 256, 128], layernorm=False, basis="wendland",
+                         output_dim=1, B=257, seed=18),
+}
+
+# Cases small enough that the fp32 reference arrays are stored next to the float64 truth.
+FULL_CASES = ["tiny9", "tiny9_ln_p3"]
+# Tensors with more elements than this are stored as digests (samples + row/col sums + norm).
+DIGEST_ABOVE = 20000
+
+CALIBRATION = {"wendland": 1.0, "gaussian": 0.223477, "triangular": 0.654714}
+
+
+def make_inputs(cfg):
+    """Deterministic (X, coords, t, y) float32 arrays for a case, with the edge rows first:
+    on-knot points, points at exactly r = 1 from a knot, out-of-domain points."""
+    rs = np.random.RandomState(cfg["seed"])
+    B, p = cfg["B"], cfg["p"]
+    coords = rs.uniform(0.0, 1.0, size=(B, 2)).astype(np.float32)
+    side0 = int(math.isqrt(cfg["k_spatial_centers"][0]))
+    bw0 = np.float32(2.5 * (1.0 / (side0 - 1) if side0 > 1 else 1.0))
+    edge = np.array([
+        [0.0, 0.0], [1.0, 1.0], [0.5, 0.5],            # on knots of every odd-sided grid
+        [min(float(bw0), 1.0), 0.0],                   # r == 1 from knot (0,0) at level 0
+        [-0.1, 0.3], [1.2, 1.05],                      # outside [0,1]^2
+    ], dtype=np.float32)
+    n_edge = min(len(edge), max(B - 1, 0))
+    coords[:n_edge] = edge[:n_edge]
+    T = 100
+    t = (rs.randint(0, T, size=(B, 1)).astype(np.float32) / np.float32(T - 1)).astype(np.float32)
+    if B > 2:
+        t[0, 0], t[1, 0] = 0.0, 1.0
+    x, yy = coords[:, 0].astype(np.float64), coords[:, 1].astype(np.float64)
+    y = (np.sin(4 * np.pi * x) * np.cos(3 * np.pi * yy) * (1 + 0.5 * np.sin(2 * np.pi * t[:, 0]))
+         + 0.1 * rs.standard_normal(B)).astype(np.float32).reshape(B, 1)
+    X = rs.standard_normal((B, p)).astype(np.float32)
+    return X, coords, t, y
+
+
+def state_layout(cfg):
+    """[(key, shape, kind)] for the trainable tensors in nn.Sequential index order
+    (st_interp.py:656-690: Linear [, LayerNorm], ReLU [, Dropout]; dropout=0 in all cases)."""
+    D = cfg["p"] + sum(cfg["k_spatial_centers"]) + sum(cfg["k_temporal_centers"])
+    out = []
+    idx, prev = 0, D
+    for h in cfg["hidden_dims"]:
+        out.append((f"mlp.{idx}.weight", (h, prev), "lin_w"))
+        out.append((f"mlp.{idx}.bias", (h,), "lin_b"))
+        idx += 1
+        if cfg["layernorm"]:
+            out.append((f"mlp.{idx}.weight", (h,), "ln_g"))
+            out.append((f"mlp.{idx}.bias", (h,), "ln_b"))
+            idx += 1
+        idx += 1  # ReLU
+        prev = h
+    out.append((f"mlp.{idx}.weight", (cfg["output_dim"], prev), "lin_w"))
+    out.append((f"mlp.{idx}.bias", (cfg["output_dim"],), "lin_b"))
+    return out
+
+
+def make_state(cfg):
+    """Deterministic float32 parameters {key: ndarray}; Linear ~ U(+-1/sqrt(fan_in)) as the torch
+    default would give in distribution, LayerNorm gamma/beta perturbed away from (1, 0) so that
+    their gradients are exercised."""
+    rs = np.random.RandomState(cfg["seed"] + 1000)
+    st = {}
+    fan_in = None
+    for key, shape, kind in state_layout(cfg):
+        if kind == "lin_w":
+            fan_in = shape[1]
+            b = 1.0 / math.sqrt(fan_in)
+            st[key] = rs.uniform(-b, b, size=shape).astype(np.float32)
+        elif kind == "lin_b":
+            b = 1.0 / math.sqrt(fan_in)
+            st[key] = rs.uniform(-b, b, size=shape).astype(np.float32)
+        elif kind == "ln_g":
+            st[key] = (1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32)
+        else:
+            st[key] = (0.05 * rs.standard_normal(shape)).astype(np.float32)
+    return st
+
+
+# Hyper-parameters of the G6 optimiser-step golden (train_st_interp.py:506-510,696-712; ema.py:52-66)
+OPT = dict(lr=2e-2, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_clip=10.0,
+           ema_decay=0.99, steps=3)
+
+
+def digest_positions(shape, n, seed):
+    """n deterministic flat positions inside an array of `shape` (for big-gradient digests)."""
+    rs = np.random.RandomState(seed)
+    size = int(np.prod(shape))
+    return np.sort(rs.randint(0, size, size=n)).astype(np.int64)

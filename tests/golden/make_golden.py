@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the REAL reference.
+
+Runs only in the build container (needs /root/reference on disk); the GPU box never runs it and
+never sees the reference.  The committed .npz files hold data only: the reference's outputs on
+the deterministic inputs of cases.py (inputs/weights are rebuilt from seeds on the test side).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+What is captured:
+  G1 knots.npz        knot tables of SpatialBasisEmbedding._init_uniform / TemporalBasisEmbedding
+  G2/G3/G4 <case>.npz phi, psi, features (fp32 as the reference computes them, fp32 with cdist's
+                      direct mode, and float64 "truth" from the same module under .double())
+  G5 <case>.npz       y, MSE loss, every parameter gradient (fp32 + float64)
+  G6 <case>.npz       parameters + EMA shadow after OPT['steps'] x (fwd, MSE, bwd, clip, AdamW, EMA)
+"""
+import copy
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+
+import cases  # noqa: E402
+from stnf.models.st_interp import (STInterpMLP, SpatialBasisEmbedding,  # noqa: E402
+                                   TemporalBasisEmbedding)
+from stnf.utils.ema import ModelEMA  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def store(out, prefix, key, a64, a32, seed, keep32):
+    """Full float64 truth for small tensors, a digest (samples + row/column sums + norm) for
+    big ones; the fp32 reference run is kept only as its error against the truth."""
+    d = a32.astype(np.float64) - a64
+    out[f"{prefix}err32_maxabs/{key}"] = np.float64(np.abs(d).max())
+    out[f"{prefix}err32_rell2/{key}"] = np.float64(np.linalg.norm(d.ravel())
+                                                   / max(np.linalg.norm(a64.ravel()), 1e-300))
+    out[f"{prefix}norm64/{key}"] = np.float64(np.linalg.norm(a64.ravel()))
+    if a64.size <= cases.DIGEST_ABOVE:
+        out[f"{prefix}64/{key}"] = a64
+        if keep32:
+            out[f"{prefix}32/{key}"] = a32
+    else:
+        pos = cases.digest_positions(a64.shape, 2048, seed)
+        out[f"{prefix}64s/{key}"] = a64.ravel()[pos]
+        if a64.ndim == 2:
+            out[f"{prefix}colsum64/{key}"] = a64.sum(0)
+            out[f"{prefix}rowsum64/{key}"] = a64.sum(1)
+
+
+def gen_knots():
+    out = {}
+    for side in cases.KNOT_SIDES:
+        m = SpatialBasisEmbedding(n_centers=[side * side])
+        c = m.centers.numpy()
+        bw = m.bandwidths.numpy()
+        out[f"s{side}_lin"] = torch.linspace(0, 1, side).numpy()
+        out[f"s{side}_bw"] = bw[:1].copy()
+        out[f"s{side}_centers_sha"] = np.frombuffer(bytes.fromhex(sha(c)), dtype=np.uint8)
+        out[f"s{side}_bw_sha"] = np.frombuffer(bytes.fromhex(sha(bw)), dtype=np.uint8)
+        if side <= 11:
+            out[f"s{side}_centers"] = c.copy()
+    # multi-level concatenation order (level offsets)
+    m = SpatialBasisEmbedding(n_centers=[25, 81, 121])
+    out["ml_centers"] = m.centers.numpy().copy()
+    out["ml_bw"] = m.bandwidths.numpy().copy()
+    for n in cases.TEMPORAL_NS:
+        tm = TemporalBasisEmbedding(n_centers=[n])
+        out[f"t{n}_centers"] = tm.centers.numpy().copy()
+        out[f"t{n}_bw"] = tm.bandwidths.numpy().copy()
+    tm = TemporalBasisEmbedding(n_centers=[10, 15, 45])
+    out["tml_centers"] = tm.centers.numpy().copy()
+    out["tml_bw"] = tm.bandwidths.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "knots.npz"), **out)
+    print("knots.npz", len(out), "arrays")
+
+
+def build(cfg):
+    model = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"],
+                        k_temporal_centers=cfg["k_temporal_centers"],
+                        hidden_dims=cfg["hidden_dims"], dropout=0.0, layernorm=cfg["layernorm"],
+                        spatial_learnable=False, spatial_init_method="uniform",
+                        spatial_basis_function=cfg["basis"], output_dim=cfg["output_dim"])
+    st = cases.make_state(cfg)
+    sd = model.state_dict()
+    keys = [k for k in sd if k.startswith("mlp.")]
+    assert sorted(keys) == sorted(st.keys()), (keys, list(st))
+    for k, v in st.items():
+        assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(sd)
+    return model
+
+
+def run_once(model, X, coords, t, y):
+    model.train()
+    model.zero_grad()
+    phi = model.spatial_basis(coords)
+    psi = model.temporal_basis(t)
+    yp = model(X, coords, t)
+    loss = torch.nn.MSELoss()(yp, y)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    return phi.detach(), psi.detach(), yp.detach(), loss.detach(), grads
+
+
+def opt_steps(model, X, coords, t, y):
+    o = cases.OPT
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=o["lr"],
+                            weight_decay=o["weight_decay"], betas=o["betas"], eps=o["eps"])
+    ema = ModelEMA(model, decay=o["ema_decay"])
+    crit = torch.nn.MSELoss()
+    losses = []
+    model.train()
+    for _ in range(o["steps"]):
+        opt.zero_grad()
+        loss = crit(model(X, coords, t), y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), o["grad_clip"])
+        opt.step()
+        ema.update(model)
+        losses.append(float(loss))
+    params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    shadow = {n: v.detach().clone() for n, v in ema.shadow.items()}
+    return params, shadow, np.array(losses, dtype=np.float64)
+
+
+def gen_case(name):
+    cfg = cases.MODEL_CASES[name]
+    X, coords, t, y = (torch.from_numpy(a) for a in cases.make_inputs(cfg))
+    full = name in cases.FULL_CASES
+    out = {}
+
+    m32 = build(cfg)
+    phi32, psi32, y32, loss32, g32 = run_once(m32, X, coords, t, y)
+
+    m64 = build(cfg).double()
+    phi64, psi64, y64, loss64, g64 = run_once(m64, X.double(), coords.double(), t.double(),
+                                              y.double())
+
+    # cdist direct mode + the reference's own basis function (SURVEY §7 parity protocol (ii))
+    sb = m32.spatial_basis
+    dist = torch.cdist(coords, sb.centers, compute_mode="donot_use_mm_for_euclid_dist")
+    r = dist / (sb.bandwidths * sb.CALIBRATION_FACTORS[sb.basis_function])
+    phi32d = {"wendland": sb._wendland, "gaussian": sb._gaussian,
+              "triangular": sb._triangular}[sb.basis_function](r)
+
+    out["y32"], out["y64"] = y32.numpy(), y64.numpy()
+    out["loss32"], out["loss64"] = np.float32(loss32.item()), np.float64(loss64.item())
+    out["psi64"] = psi64.numpy()
+    out["psi_err32_maxabs"] = np.float64((psi32.double() - psi64).abs().max().item())
+    out["phi_rowsum64"] = phi64.sum(1).numpy()
+    out["phi_err32_maxabs"] = np.float64((phi32.double() - phi64).abs().max().item())
+    out["phi_err32d_maxabs"] = np.float64((phi32d.double() - phi64).abs().max().item())
+    out["y_err32_maxabs"] = np.float64((y32.double() - y64).abs().max().item())
+    out["phi64_nnz_per_row"] = (phi64 != 0).sum(1).numpy().astype(np.int32)
+    if phi64.numel() <= 50000:
+        out["phi64"] = phi64.numpy()
+        if full:
+            out["phi32"], out["phi32d"] = phi32.numpy(), phi32d.numpy()
+    else:
+        # sparse truth (row, col, value) for the first 64 rows
+        sub = phi64[:min(64, cfg["B"])]
+        nz = (sub != 0).nonzero()
+        out["phi64_nz_rc"] = nz.numpy().astype(np.int32)
+        out["phi64_nz_val"] = sub[nz[:, 0], nz[:, 1]].numpy()
+    for k in g64:
+        store(out, "g", k, g64[k].numpy(), g32[k].numpy(), cfg["seed"] + 7, full)
+
+    # G6 optimiser steps (float64 truth + fp32 as the reference runs it)
+    p32, s32, l32 = opt_steps(build(cfg), X, coords, t, y)
+    p64, s64, l64 = opt_steps(build(cfg).double(), X.double(), coords.double(), t.double(),
+                              y.double())
+    out["opt_losses32"], out["opt_losses64"] = l32, l64
+    for k in p64:
+        store(out, "p", k, p64[k].numpy(), p32[k].numpy(), cfg["seed"] + 7, full)
+        store(out, "ema", k, s64[k].numpy(), s32[k].numpy(), cfg["seed"] + 7, full)
+
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB  phi_err32={out['phi_err32_maxabs']:.2e} "
+          f"phi_err32d={out['phi_err32d_maxabs']:.2e} y_err32={out['y_err32_maxabs']:.2e}")
+
+
+if __name__ == "__main__":
+    gen_knots()
+    for nm in cases.MODEL_CASES:
+        gen_case(nm)

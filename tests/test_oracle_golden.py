@@ -1,0 +1,176 @@
+"""Pins the CPU oracle (oracle/stdadk_oracle.py, oracle/torch_port.py) against golden vectors
+generated from the real reference (tests/golden/make_golden.py).  CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from golden import cases
+from oracle import stdadk_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ G1 knot tables (bit-exact)
+@pytest.mark.parametrize("side", cases.KNOT_SIDES)
+def test_knot_table_bit_exact(side):
+    g = load("knots")
+    lin = orc.linspace_f32(0.0, 1.0, side)
+    assert lin.dtype == np.float32 and np.array_equal(lin.view(np.uint32), g[f"s{side}_lin"].view(np.uint32))
+    c, bw, sides = orc.uniform_knots([side * side])
+    assert sides == [side]
+    assert np.array_equal(sha(c), g[f"s{side}_centers_sha"])
+    assert np.array_equal(sha(bw), g[f"s{side}_bw_sha"])
+    assert np.array_equal(bw[:1].view(np.uint32), g[f"s{side}_bw"].view(np.uint32))
+    if side <= 11:
+        assert np.array_equal(c, g[f"s{side}_centers"])
+    # knot index k = ix*side + iy
+    k = 1 * side + 2
+    assert c[k, 0] == lin[1] and c[k, 1] == lin[2]
+
+
+def test_knot_table_multilevel_and_temporal():
+    g = load("knots")
+    c, bw, sides = orc.uniform_knots([25, 81, 121])
+    assert np.array_equal(c, g["ml_centers"]) and np.array_equal(bw, g["ml_bw"]) and sides == [5, 9, 11]
+    for n in cases.TEMPORAL_NS:
+        tc, tb = orc.temporal_knots([n])
+        assert np.array_equal(tc, g[f"t{n}_centers"]) and np.array_equal(tb, g[f"t{n}_bw"])
+    tc, tb = orc.temporal_knots([10, 15, 45])
+    assert np.array_equal(tc, g["tml_centers"]) and np.array_equal(tb, g["tml_bw"])
+
+
+def test_knot_errors():
+    with pytest.raises(AssertionError):
+        orc.uniform_knots([10])
+    with pytest.raises(ValueError):
+        orc.spatial_basis(np.zeros((1, 2)), np.zeros((1, 2)), np.ones(1), basis="nope")
+
+
+# ------------------------------------------------------------------ G2-G5 float64 truth
+def _digest_check(got, g, prefix, key, seed, rtol):
+    got = np.asarray(got, dtype=np.float64)
+    norm = float(g[f"{prefix}norm64/{key}"])
+    if f"{prefix}64/{key}" in g:
+        ref = g[f"{prefix}64/{key}"]
+        assert got.shape == ref.shape
+        assert np.linalg.norm((got - ref).ravel()) <= rtol * max(norm, 1e-30), (prefix, key)
+    else:
+        pos = cases.digest_positions(got.shape, 2048, seed)
+        ref = g[f"{prefix}64s/{key}"]
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(got.ravel()[pos] - ref).max() <= rtol * scale * 10, (prefix, key)
+        assert abs(np.linalg.norm(got.ravel()) - norm) <= rtol * norm
+        if got.ndim == 2:
+            cs, rsum = g[f"{prefix}colsum64/{key}"], g[f"{prefix}rowsum64/{key}"]
+            # (sums over the LayerNorm-ed output dim cancel to ~0, so scale by the tensor norm)
+            assert np.abs(got.sum(0) - cs).max() <= rtol * norm * 10
+            assert np.abs(got.sum(1) - rsum).max() <= rtol * norm * 10
+
+
+@pytest.mark.parametrize("name", list(cases.MODEL_CASES))
+def test_oracle_matches_reference_float64(name):
+    cfg = cases.MODEL_CASES[name]
+    g = load(name)
+    X, coords, t, y = cases.make_inputs(cfg)
+    params = cases.make_state(cfg)
+    yp, cache, phi, psi, feat = orc.model_forward(X, coords, t, params, cfg, np.float64)
+    D = cfg["p"] + sum(cfg["k_spatial_centers"]) + sum(cfg["k_temporal_centers"])
+    assert feat.shape == (cfg["B"], D)
+    # G4 column order [X | phi | psi]
+    p, Ks = cfg["p"], phi.shape[1]
+    if p:
+        assert np.array_equal(feat[:, :p], X.astype(np.float64))
+    assert np.array_equal(feat[:, p:p + Ks], phi) and np.array_equal(feat[:, p + Ks:], psi)
+    assert np.abs(psi - g["psi64"]).max() < 1e-14
+    assert np.abs(phi.sum(1) - g["phi_rowsum64"]).max() < 1e-11
+    if "phi64" in g:
+        assert np.abs(phi - g["phi64"]).max() < 1e-12   # ref f64 uses cdist's expansion
+    else:
+        rc, val = g["phi64_nz_rc"], g["phi64_nz_val"]
+        assert np.abs(phi[rc[:, 0], rc[:, 1]] - val).max() < 1e-12
+    assert np.array_equal((phi != 0).sum(1).astype(np.int32), g["phi64_nnz_per_row"])
+    assert np.abs(yp - g["y64"]).max() < 1e-11
+    loss = orc.mse(yp, y)
+    assert abs(loss - float(g["loss64"])) < 1e-12 * max(1.0, abs(loss))
+    grads = orc.mlp_mse_backward(yp, y, cache, params, len(cfg["hidden_dims"]), cfg["layernorm"])
+    for k in params:
+        _digest_check(grads[k], g, "g", k, cfg["seed"] + 7, 1e-10)
+
+
+@pytest.mark.parametrize("name", list(cases.MODEL_CASES))
+def test_oracle_optimizer_steps(name):
+    """G6: OPT['steps'] x (fwd, MSE, bwd, clip, AdamW, EMA) in float64."""
+    cfg = cases.MODEL_CASES[name]
+    g = load(name)
+    o = cases.OPT
+    X, coords, t, y = cases.make_inputs(cfg)
+    params = {k: v.astype(np.float64) for k, v in cases.make_state(cfg).items()}
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v2 = {k: np.zeros_like(v) for k, v in params.items()}
+    shadow = {k: v.copy() for k, v in params.items()}
+    losses = []
+    for s in range(1, o["steps"] + 1):
+        yp, loss, grads = orc.train_step_grads(X, coords, t, y, params, cfg)
+        losses.append(loss)
+        orc.adamw_ema_step(params, grads, m, v2, shadow, s, o["lr"], o["weight_decay"], o["betas"],
+                           o["eps"], o["grad_clip"], o["ema_decay"])
+    assert np.abs(np.array(losses) - g["opt_losses64"]).max() < 1e-9
+    for k in params:
+        _digest_check(params[k], g, "p", k, cfg["seed"] + 7, 1e-9)
+        _digest_check(shadow[k], g, "ema", k, cfg["seed"] + 7, 1e-9)
+
+
+# ------------------------------------------------------------------ integer bookkeeping
+@pytest.mark.parametrize("name", ["default227", "c2_b257"])
+def test_knot_windows_cover_support(name):
+    """The WINDOW x WINDOW block of knot_windows() contains every non-zero knot of the truth."""
+    cfg = cases.MODEL_CASES[name]
+    _, coords, _, _ = cases.make_inputs(cfg)
+    centers, bw, sides = orc.uniform_knots(cfg["k_spatial_centers"])
+    phi = orc.spatial_basis(coords, centers, bw, "wendland")
+    ix0, iy0, col0, offs = orc.knot_windows(coords, sides, cfg["p"])
+    covered = np.zeros_like(phi, dtype=bool)
+    for l, side in enumerate(sides):
+        w = min(orc.WINDOW, side)
+        for b in range(coords.shape[0]):
+            for dx in range(w):
+                k0 = offs[l] + (ix0[b, l] + dx) * side + iy0[b, l]
+                covered[b, k0:k0 + w] = True
+        assert np.array_equal(col0[:, l], cfg["p"] + offs[l] + ix0[:, l] * side + iy0[:, l])
+    assert not np.any((phi != 0) & ~covered)
+
+
+# ------------------------------------------------------------------ torch port (timed baseline)
+@pytest.mark.parametrize("name", ["tiny9", "tiny9_ln_p3", "default227", "default227_gauss",
+                                  "default227_tri", "c2_b257_noln"])
+def test_torch_port_matches_reference_fp32(name):
+    import torch
+    from oracle import torch_port as tp
+    torch.set_num_threads(4)
+    cfg = cases.MODEL_CASES[name]
+    g = load(name)
+    X, coords, t, y = (torch.from_numpy(a) for a in cases.make_inputs(cfg))
+    model = tp.PortModel(cfg, state=cases.make_state(cfg))
+    assert sorted(model.params) == sorted(cases.make_state(cfg))
+    yp = model.forward(X, coords, t)
+    loss = torch.nn.functional.mse_loss(yp, y)
+    # same op sequence as the reference => agrees with the reference's own fp32 run to rounding
+    scale = max(float(np.abs(g["y64"]).max()), 1.0)
+    assert np.abs(yp.detach().numpy() - g["y32"]).max() <= 2e-6 * scale
+    assert abs(float(loss.detach()) - float(g["loss32"])) <= 2e-6 * max(1.0, float(g["loss32"]))
+    loss.backward()
+    for k, pten in model.params.items():
+        if f"g64/{k}" in g:
+            ref = g[f"g64/{k}"]
+            err = np.abs(pten.grad.numpy() - ref).max()
+            assert err <= max(2 * float(g[f"gerr32_maxabs/{k}"]), 1e-6 * np.abs(ref).max() + 1e-9), k
