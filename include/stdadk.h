@@ -1,0 +1,156 @@
+/*
+ * stdadk.h — C ABI of libstdadk.so, the MI355X (gfx950) implementation of ST-DADK's
+ * spatio-temporal interpolation hot path.
+ *
+ * The reference (STLABTW/ST-DADK) is pure Python on PyTorch and has no FFI layer; the boundary its
+ * driver sees is the nn.Module surface of stnf/models/st_interp.py.  Each entry point below names
+ * the reference function (file:line, relative to the reference root) whose arithmetic it replaces.
+ * The Python face (st-dadk_amd/stnf) binds these symbols with ctypes; INTEGRATION.md shows the
+ * stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer (hipMalloc / torch
+ *     allocator) unless the parameter says "host".  Inputs are borrowed, outputs are written into
+ *     caller-provided buffers; the library allocates nothing and keeps no global mutable state.
+ *   - `stream` is a hipStream_t (0 = default stream).  Every call only enqueues work on it:
+ *     no host<->device sync, no host read of device scalars => hipGraph-capturable.
+ *   - all matrices are row-major fp32; `ld*` is the row stride in elements.
+ *   - return value: 0 on success; <0 argument error (STDADK_E_*); >0 a hipError_t.
+ *     stdadk_last_error() returns a thread-local message for the last non-zero return.
+ */
+#ifndef STDADK_H
+#define STDADK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STDADK_ABI_VERSION 1
+#define STDADK_MAX_HIDDEN 8
+#define STDADK_MAX_LEVELS 8
+
+#define STDADK_E_ARG (-1)     /* null pointer / negative size / bad enum       */
+#define STDADK_E_SHAPE (-2)   /* shapes inconsistent with the descriptor      */
+#define STDADK_E_ALIGN (-3)   /* buffer not aligned as documented             */
+#define STDADK_E_WORKSPACE (-4) /* workspace smaller than *_workspace_bytes() */
+
+typedef void *stdadk_stream_t; /* hipStream_t */
+
+/* SpatialBasisEmbedding.basis_function, stnf/models/st_interp.py:56-60,451-458 */
+enum { STDADK_BASIS_WENDLAND = 0, STDADK_BASIS_GAUSSIAN = 1, STDADK_BASIS_TRIANGULAR = 2 };
+
+int stdadk_abi_version(void);
+const char *stdadk_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * A2-A5  feature builder (materialising):  out[b, :] = [ X[b, 0:p] | phi(coords[b]) | psi(t[b]) ]
+ *
+ * Replaces SpatialBasisEmbedding.forward + _wendland/_gaussian/_triangular
+ * (stnf/models/st_interp.py:433-491), TemporalBasisEmbedding.forward (:583-596) and the
+ * torch.cat of STInterpMLP.forward (:843-846).
+ *   phi[b,k] = f( sqrt((x-cx_k)^2+(y-cy_k)^2) / (bw_k * cal) ),  cal = 1 / 0.223477 / 0.654714
+ *   psi[b,j] = exp(-0.5 * ((t-c_j)/bw_j)^2)
+ * coords [B,2], t [B] (the reference's (B,1) column), X [B,p] or NULL when p == 0,
+ * s_centers [Ks,2], s_bw [Ks], t_centers [Kt], t_bw [Kt]; Ks or Kt may be 0.
+ * out [B, ld_out], ld_out >= p+Ks+Kt; columns beyond p+Ks+Kt (row padding) are zero-filled.
+ * ------------------------------------------------------------------------------------------ */
+int stdadk_rbf_build_f32(const float *coords, const float *t, const float *X, int64_t B, int32_t p,
+                         const float *s_centers, const float *s_bw, int64_t Ks, int32_t basis,
+                         const float *t_centers, const float *t_bw, int64_t Kt, float *out,
+                         int64_t ld_out, stdadk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A6  MLP  (Linear -> LayerNorm -> ReLU -> Dropout) x L -> Linear      st_interp.py:656-690,880
+ * ------------------------------------------------------------------------------------------ */
+typedef struct stdadk_mlp_desc {
+  int32_t n_hidden;                  /* L, 0..STDADK_MAX_HIDDEN                               */
+  int32_t in_dim;                    /* D = p + Ks + Kt                                       */
+  int32_t hidden[STDADK_MAX_HIDDEN]; /* hidden_dims                                           */
+  int32_t out_dim;                   /* Q (1 for MSE regression)                              */
+  int32_t layernorm;                 /* 0/1; eps below (nn.LayerNorm default 1e-5)            */
+  float ln_eps;
+  float dropout_p;                   /* 0 => no dropout layers                                */
+} stdadk_mlp_desc;
+
+/* Device pointers of the parameters / their gradients; layer l = 0..L-1 are the hidden Linear
+ * (+LayerNorm) layers, layer L is the output Linear.  W[l] is (out,in) row-major contiguous as
+ * nn.Linear stores it; ln_g/ln_b are NULL when layernorm == 0. */
+typedef struct stdadk_mlp_tensors {
+  float *W[STDADK_MAX_HIDDEN + 1];
+  float *b[STDADK_MAX_HIDDEN + 1];
+  float *ln_g[STDADK_MAX_HIDDEN];
+  float *ln_b[STDADK_MAX_HIDDEN];
+} stdadk_mlp_tensors;
+
+/* Bytes of workspace stdadk_mlp_forward_f32/backward_f32 need for B rows (saved activations +
+ * split-K slabs).  The same workspace must be passed to backward untouched. */
+size_t stdadk_mlp_workspace_bytes(const stdadk_mlp_desc *desc, int64_t B);
+
+/* y_pred[B,Q] = mlp(features[B, ldf]).  `training` != 0 applies dropout (keep-mask from the
+ * counter-based generator keyed by drop_seed, or from drop_mask[l] (uint8 [B,h_l], 1 = keep) when
+ * that host array of device pointers is non-NULL) and saves what backward needs in `workspace`. */
+int stdadk_mlp_forward_f32(const stdadk_mlp_desc *desc, const stdadk_mlp_tensors *params,
+                           const float *features, int64_t ldf, int64_t B, float *y_pred,
+                           void *workspace, size_t workspace_bytes, int32_t training,
+                           uint64_t drop_seed, const uint8_t *const *drop_mask,
+                           stdadk_stream_t stream);
+
+/* A8  loss.backward() through A6 (scripts/train_st_interp.py:693): given dY[B,Q] = dLoss/dy_pred,
+ * writes every parameter gradient into `grads` (overwrite, not accumulate).  Knots are buffers in
+ * the fixed-basis model, so no gradient flows into the features and dX of layer 0 is skipped. */
+int stdadk_mlp_backward_f32(const stdadk_mlp_desc *desc, const stdadk_mlp_tensors *params,
+                            const stdadk_mlp_tensors *grads, const float *features, int64_t ldf,
+                            int64_t B, const float *dY, void *workspace, size_t workspace_bytes,
+                            uint64_t drop_seed, const uint8_t *const *drop_mask,
+                            stdadk_stream_t stream);
+
+/* A7  nn.MSELoss() (scripts/train_st_interp.py:549,621) fused with its gradient:
+ *   loss_sum[0] += sum((y_pred-y)^2)   (caller divides by the global element count)
+ *   dY[i] = 2*(y_pred[i]-y[i])*grad_scale          (grad_scale = 1/(B*Q) for the plain mean)
+ * n = B*Q elements.  dY may be NULL (evaluation); loss_sum may be NULL. */
+int stdadk_mse_f32(const float *y_pred, const float *y, int64_t n, float grad_scale, float *dY,
+                   float *loss_sum, stdadk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A9  clip_grad_norm_ + AdamW + EMA on flat fp32 buffers of n elements
+ * (scripts/train_st_interp.py:696-712, stnf/utils/ema.py:52-66, torch.optim.AdamW).
+ *   stdadk_sumsq_f32 :  out[0] += sum(g^2)      (out zeroed by the caller; after an all-reduce of
+ *                       the gradients this is the post-reduce global norm the clip must use)
+ *   stdadk_adamw_ema_f32: coef = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) if max_norm > 0 else 1
+ *       g' = g*coef*grad_mul; p *= 1-lr*wd; m = b1*m+(1-b1)*g'; v = b2*v+(1-b2)*g'^2;
+ *       p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps);
+ *       ema = decay*ema + (1-decay)*p   (skipped when ema == NULL)
+ *   lr is read from the device scalar lr_dev[0] when non-NULL (graph-replayable schedules),
+ *   else from `lr`.  `step` is the 1-based step count (host value) or read from step_dev[0]
+ *   (int32, incremented by the kernel) when non-NULL.
+ * ------------------------------------------------------------------------------------------ */
+int stdadk_sumsq_f32(const float *g, int64_t n, float *out, stdadk_stream_t stream);
+
+int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
+                         float lr, const float *lr_dev, float beta1, float beta2, float eps,
+                         float weight_decay, int32_t step, int32_t *step_dev, float max_norm,
+                         const float *sumsq, float grad_mul, float ema_decay,
+                         stdadk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The fp32 MFMA GEMM the Linear layers are built from (nn.Linear forward / autograd backward:
+ * st_interp.py:660,689), exposed so that tests and the roofline measurement can drive it directly.
+ *   C[M,N] (+bias[N]) = sum_k Aop[m][k] * Bop[k][n]
+ *   a_km == 0: Aop[m][k] = A[m*lda + k]      a_km != 0: Aop[m][k] = A[k*lda + m]
+ *   b_km == 0: Bop[k][n] = B[n*ldb + k]      b_km != 0: Bop[k][n] = B[k*ldb + n]
+ * (a_km != 0 with b_km == 0 is not built.)  workspace: stdadk_gemm_workspace_bytes(M,N,K) bytes
+ * of split-K slab space (may be 0 / NULL when the shape does not split).
+ * ------------------------------------------------------------------------------------------ */
+size_t stdadk_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K);
+
+int stdadk_gemm_f32(const float *A, int64_t lda, int32_t a_km, const float *B, int64_t ldb,
+                    int32_t b_km, int32_t M, int32_t N, int32_t K, const float *bias, float *C,
+                    int64_t ldc, void *workspace, size_t workspace_bytes, stdadk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STDADK_H */

@@ -1,0 +1,59 @@
+// Shared helpers of libstdadk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/stdadk.h"
+
+namespace stdadk {
+
+void set_error(const char *fmt, ...);
+
+#define STDADK_REQUIRE(cond, code, ...)          \
+  do {                                            \
+    if (!(cond)) {                                \
+      ::stdadk::set_error(__VA_ARGS__);           \
+      return (code);                              \
+    }                                             \
+  } while (0)
+
+// Launch errors surface as positive hipError_t values.
+#define STDADK_CHECK_LAUNCH(what)                                             \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      ::stdadk::set_error("%s: %s", what, hipGetErrorString(e__));            \
+      return (int)e__;                                                        \
+    }                                                                         \
+  } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Counter-based keep-mask generator for dropout: one 32-bit hash per (seed, layer, element).
+// Stateless, so backward regenerates exactly the mask forward used.
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, int layer, int64_t elem, float p) {
+  uint32_t h = mix32(seed ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(layer + 1)) ^ ((uint64_t)elem * 0xD1B54A32D192ED03ULL));
+  // uniform in [0,1): keep when u >= p  (P(keep) = 1-p)
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+}  // namespace stdadk

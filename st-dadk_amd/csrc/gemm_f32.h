@@ -1,0 +1,44 @@
+// fp32 MFMA GEMM used by the MLP layers (exact fp32: v_mfma_f32_32x32x2_f32 is a k-ordered fma chain).
+#pragma once
+#include "common.h"
+
+namespace stdadk {
+
+// C[M,N] (+bias[N]) = sum_k Aop[m][k] * Bop[k][n]
+//   a_km == false : Aop[m][k] = A[m*lda + k]   (row-major M x K, K contiguous)
+//   a_km == true  : Aop[m][k] = A[k*lda + m]   (stored K x M, reduction index is the row)
+//   b_km == false : Bop[k][n] = B[n*ldb + k]   (stored N x K — nn.Linear weight layout)
+//   b_km == true  : Bop[k][n] = B[k*ldb + n]   (stored K x N)
+// splits > 1: split s covers k in [s*kps, (s+1)*kps) and writes its partial tile to
+//   slab + s*slab_stride (row stride N, no bias); the caller sums the slabs.
+struct GemmArgs {
+  const float *A;
+  int64_t lda;
+  const float *B;
+  int64_t ldb;
+  float *C;
+  int64_t ldc;
+  const float *bias;  // may be NULL; only applied when splits == 1
+  int M, N, K;
+  int splits;         // >= 1
+  int kps;            // K per split, multiple of 32 (ignored when splits == 1)
+  float *slab;        // splits * slab_stride floats when splits > 1
+  int64_t slab_stride;
+};
+
+// Picks a split count so the launch has >= ~256 workgroups; returns splits and sets kps.
+int gemm_pick_splits(int M, int N, int K, int *kps, bool big_tile);
+bool gemm_use_big_tile(int M, int N);
+int launch_gemm_f32(const GemmArgs &g, bool a_km, bool b_km, hipStream_t st);
+
+// Floats of split-K slab workspace gemm_run() needs for this shape (0 when it does not split).
+size_t gemm_slab_floats(int M, int N, int K);
+
+// C = Aop * Bop (+bias): picks tile and split, launches, and sums the partial slabs into C unless
+// `keep_slabs` (then the caller's next kernel consumes `*splits_out` slabs of M*N floats itself;
+// with one split the un-biased product is in C).
+int gemm_run(const float *A, int64_t lda, bool a_km, const float *Bm, int64_t ldb, bool b_km, int M, int N,
+             int K, const float *bias, float *C, int64_t ldc, float *slab, bool keep_slabs,
+             int *splits_out, hipStream_t st);
+
+}  // namespace stdadk

@@ -1,0 +1,359 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32, 64 FLOP/clk/SIMD).
+//
+// One workgroup = 4 waves (2x2) computes a BM x BN tile of C, each wave (BM/2)x(BN/2) as
+// (BM/64)x(BN/64) MFMA tiles of 32x32.  K is walked in steps of BK = 32 through one LDS stage with
+// register prefetch of the next step (global -> VGPR during the MFMAs of the current step).
+//
+// LDS images and fragment reads (bank rules: MI355X guide, "LDS"):
+//   K-contiguous operand  (rows x BK, row stride BK+4 floats): one ds_read_b128 per lane gives 4
+//     consecutive k of its row; the 144-byte row stride spreads the 16 lanes of a b128 group over
+//     all 64 banks (conflict-free).
+//   K-major operand (BK x rows, row stride = rows): ds_read_b32, 32 lanes read 32 consecutive
+//     floats of one k-row (conflict-free).
+// The MFMA sums k over the two lane halves (k = l>>5); a lane half h uses k = 8*s + 4*h + e for
+// MFMA e of sub-step s, for BOTH operands, so any k order is fine as long as A and B agree.
+#include "gemm_f32.h"
+
+namespace stdadk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int GT = 256;  // threads
+
+template <int ROWS, bool KM>
+struct TileGeom {
+  static constexpr int STRIDE = KM ? ROWS : (BK + 4);
+  static constexpr int SIZE = KM ? BK * ROWS : ROWS * (BK + 4);
+  static constexpr int ELEMS = ROWS * BK / GT;  // floats per thread per stage
+};
+
+// Global -> registers for one operand tile.  `r0` first row (m or n) of the tile, `k0` first k.
+// VEC = contiguous floats per load along the operand's contiguous dimension.
+template <int ROWS, bool KM, int VEC>
+__device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t ld, int r0, int nrows,
+                                          int k0, int kend, float *reg) {
+  const int tid = threadIdx.x;
+  constexpr int N_VEC = TileGeom<ROWS, KM>::ELEMS / VEC;
+  if (!KM) {
+    constexpr int VPR = BK / VEC;       // vectors per row
+    constexpr int RPP = GT / VPR;       // rows per pass
+#pragma unroll
+    for (int i = 0; i < N_VEC; ++i) {
+      int row = tid / VPR + i * RPP;
+      int k = k0 + (tid % VPR) * VEC;
+      bool rok = (r0 + row) < nrows;
+      const float *src = P + (int64_t)(r0 + row) * ld + k;
+      if (VEC == 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rok && k < kend) v = *reinterpret_cast<const float4 *>(src);
+        reg[i * 4 + 0] = (k + 0 < kend) ? v.x : 0.f;
+        reg[i * 4 + 1] = (k + 1 < kend) ? v.y : 0.f;
+        reg[i * 4 + 2] = (k + 2 < kend) ? v.z : 0.f;
+        reg[i * 4 + 3] = (k + 3 < kend) ? v.w : 0.f;
+      } else if (VEC == 2) {
+        float2 v = make_float2(0.f, 0.f);
+        if (rok && k < kend) v = *reinterpret_cast<const float2 *>(src);
+        reg[i * 2 + 0] = (k + 0 < kend) ? v.x : 0.f;
+        reg[i * 2 + 1] = (k + 1 < kend) ? v.y : 0.f;
+      } else {
+        reg[i] = (rok && k < kend) ? *src : 0.f;
+      }
+    }
+  } else {
+    constexpr int VPR = ROWS / VEC;     // vectors per k-row
+    constexpr int KPP = GT / VPR;       // k-rows per pass
+#pragma unroll
+    for (int i = 0; i < N_VEC; ++i) {
+      int kk = tid / VPR + i * KPP;
+      int r = r0 + (tid % VPR) * VEC;
+      bool kok = (k0 + kk) < kend;
+      const float *src = P + (int64_t)(k0 + kk) * ld + r;
+      if (VEC == 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kok && r < nrows) v = *reinterpret_cast<const float4 *>(src);
+        reg[i * 4 + 0] = (r + 0 < nrows) ? v.x : 0.f;
+        reg[i * 4 + 1] = (r + 1 < nrows) ? v.y : 0.f;
+        reg[i * 4 + 2] = (r + 2 < nrows) ? v.z : 0.f;
+        reg[i * 4 + 3] = (r + 3 < nrows) ? v.w : 0.f;
+      } else if (VEC == 2) {
+        float2 v = make_float2(0.f, 0.f);
+        if (kok && r < nrows) v = *reinterpret_cast<const float2 *>(src);
+        reg[i * 2 + 0] = (r + 0 < nrows) ? v.x : 0.f;
+        reg[i * 2 + 1] = (r + 1 < nrows) ? v.y : 0.f;
+      } else {
+        reg[i] = (kok && r < nrows) ? *src : 0.f;
+      }
+    }
+  }
+}
+
+template <int ROWS, bool KM, int VEC>
+__device__ __forceinline__ void store_tile(float *lds, const float *reg) {
+  const int tid = threadIdx.x;
+  constexpr int N_VEC = TileGeom<ROWS, KM>::ELEMS / VEC;
+  constexpr int STRIDE = TileGeom<ROWS, KM>::STRIDE;
+  if (!KM) {
+    constexpr int VPR = BK / VEC;
+    constexpr int RPP = GT / VPR;
+#pragma unroll
+    for (int i = 0; i < N_VEC; ++i) {
+      int row = tid / VPR + i * RPP;
+      int k = (tid % VPR) * VEC;
+      float *dst = lds + row * STRIDE + k;
+      if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(reg[i * 4], reg[i * 4 + 1], reg[i * 4 + 2], reg[i * 4 + 3]);
+      else if (VEC == 2) *reinterpret_cast<float2 *>(dst) = make_float2(reg[i * 2], reg[i * 2 + 1]);
+      else *dst = reg[i];
+    }
+  } else {
+    constexpr int VPR = ROWS / VEC;
+    constexpr int KPP = GT / VPR;
+#pragma unroll
+    for (int i = 0; i < N_VEC; ++i) {
+      int kk = tid / VPR + i * KPP;
+      int r = (tid % VPR) * VEC;
+      float *dst = lds + kk * STRIDE + r;
+      if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(reg[i * 4], reg[i * 4 + 1], reg[i * 4 + 2], reg[i * 4 + 3]);
+      else if (VEC == 2) *reinterpret_cast<float2 *>(dst) = make_float2(reg[i * 2], reg[i * 2 + 1]);
+      else *dst = reg[i];
+    }
+  }
+}
+
+// fragment of sub-step s for the 32 rows starting at `row` of an LDS operand image
+template <int ROWS, bool KM>
+__device__ __forceinline__ void read_frag(const float *lds, int row, int s, int lane, float *f) {
+  constexpr int STRIDE = TileGeom<ROWS, KM>::STRIDE;
+  const int r = row + (lane & 31), h = lane >> 5;
+  if (!KM) {
+    float4 v = *reinterpret_cast<const float4 *>(lds + r * STRIDE + 8 * s + 4 * h);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = lds[(8 * s + 4 * h + e) * STRIDE + r];
+  }
+}
+
+template <int BM, int BN, bool A_KM, bool B_KM, int VA, int VB>
+__global__ __launch_bounds__(GT) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  using GA = TileGeom<BM, A_KM>;
+  using GB = TileGeom<BN, B_KM>;
+  __shared__ __attribute__((aligned(16))) float lds[GA::SIZE + GB::SIZE];
+  float *As = lds, *Bs = lds + GA::SIZE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+  int kbeg = 0, kend = g.K;
+  if (g.splits > 1) {
+    kbeg = blockIdx.z * g.kps;
+    kend = min(g.K, kbeg + g.kps);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float ra[GA::ELEMS], rb[GB::ELEMS];
+  if (kbeg < kend) {
+    load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+    load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    store_tile<BM, A_KM, VA>(As, ra);
+    store_tile<BN, B_KM, VB>(Bs, rb);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, k0 + BK, kend, ra);
+      load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, k0 + BK, kend, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      float fa[TM][4], fb[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) read_frag<BM, A_KM>(As, wm + i * 32, s, lane, fa[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) read_frag<BN, B_KM>(Bs, wn + j * 32, s, lane, fb[j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: acc reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile
+  float *Cbase;
+  int64_t ldc;
+  if (g.splits > 1) {
+    Cbase = g.slab + (int64_t)blockIdx.z * g.slab_stride;
+    ldc = g.N;
+  } else {
+    Cbase = g.C;
+    ldc = g.ldc;
+  }
+  const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int col = n0 + wn + j * 32 + cl;
+      if (col >= g.N) continue;
+      float bv = (g.splits == 1 && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < g.M) Cbase[(int64_t)row * ldc + col] = acc[i][j][r] + bv;
+      }
+    }
+}
+
+static int vec_of(const float *p, int64_t ld) {
+  uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  if ((a & 15) == 0 && ld % 4 == 0) return 4;
+  if ((a & 7) == 0 && ld % 2 == 0) return 2;
+  return 1;
+}
+
+bool gemm_use_big_tile(int M, int N) {
+  // 128x128 tiles only when they alone give >= 128 workgroups; else 64x64 for parallelism
+  return (int64_t)ceil_div(M, 128) * ceil_div(N, 128) >= 128;
+}
+
+int gemm_pick_splits(int M, int N, int K, int *kps, bool big) {
+  const int t = big ? 128 : 64;
+  int64_t tiles = ceil_div(M, t) * ceil_div(N, t);
+  int s = 1;
+  if (tiles < 256) s = (int)ceil_div(256, tiles);
+  int max_s = (int)ceil_div(K, 4 * BK);   // at least 4 k-steps of work per split
+  if (max_s < 1) max_s = 1;
+  if (s > max_s) s = max_s;
+  if (s > 64) s = 64;
+  int per = (int)ceil_div(ceil_div(K, s), BK) * BK;
+  if (per < BK) per = BK;
+  s = (int)ceil_div(K, per);
+  if (s < 1) s = 1;
+  *kps = per;
+  return s;
+}
+
+template <int BM, int BN, bool A_KM, bool B_KM>
+static void launch_v(const GemmArgs &g, int va, int vb, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)g.splits);
+#define L(VA_, VB_) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KM, B_KM, VA_, VB_>), grid, dim3(GT), 0, st, g)
+  if (va == 4 && vb == 4) L(4, 4);
+  else if (va == 4 && vb == 2) L(4, 2);
+  else if (va == 4 && vb == 1) L(4, 1);
+  else if (va == 2 && vb == 4) L(2, 4);
+  else if (va == 2 && vb == 2) L(2, 2);
+  else if (va == 2 && vb == 1) L(2, 1);
+  else if (va == 1 && vb == 4) L(1, 4);
+  else if (va == 1 && vb == 2) L(1, 2);
+  else L(1, 1);
+#undef L
+}
+
+int launch_gemm_f32(const GemmArgs &g, bool a_km, bool b_km, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0) return 0;
+  STDADK_REQUIRE(g.splits >= 1 && (g.splits == 1 || (g.slab && g.kps % BK == 0)), STDADK_E_ARG,
+                 "gemm: bad split configuration");
+  const int va = vec_of(g.A, g.lda), vb = vec_of(g.B, g.ldb);
+  const bool big = gemm_use_big_tile(g.M, g.N);
+  if (big) {
+    if (!a_km && !b_km) launch_v<128, 128, false, false>(g, va, vb, st);
+    else if (!a_km && b_km) launch_v<128, 128, false, true>(g, va, vb, st);
+    else if (a_km && b_km) launch_v<128, 128, true, true>(g, va, vb, st);
+    else STDADK_REQUIRE(false, STDADK_E_ARG, "gemm: layout (a_km, !b_km) not built");
+  } else {
+    if (!a_km && !b_km) launch_v<64, 64, false, false>(g, va, vb, st);
+    else if (!a_km && b_km) launch_v<64, 64, false, true>(g, va, vb, st);
+    else if (a_km && b_km) launch_v<64, 64, true, true>(g, va, vb, st);
+    else STDADK_REQUIRE(false, STDADK_E_ARG, "gemm: layout (a_km, !b_km) not built");
+  }
+  STDADK_CHECK_LAUNCH("gemm_f32");
+  return 0;
+}
+
+
+// out[i] = sum_s slab[s*stride + i] (+ bias[i % ncol])
+__global__ void slab_sum_kernel(const float *__restrict__ slab, int splits, int64_t stride, int64_t n,
+                                const float *__restrict__ bias, int ncol, float *__restrict__ out,
+                                int64_t ld_out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+  for (int s = 0; s < splits; ++s) v += slab[(int64_t)s * stride + i];
+  int64_t r = i / ncol;
+  int c = (int)(i - r * ncol);
+  if (bias) v += bias[c];
+  out[r * ld_out + c] = v;
+}
+
+
+// C = Aop * Bop (+bias) through the split-K GEMM; partial slabs are summed into C unless
+// `keep_slabs` (the caller's next kernel consumes the slabs itself).
+int gemm_run(const float *A, int64_t lda, bool a_km, const float *Bm, int64_t ldb, bool b_km,
+                   int M, int N, int K, const float *bias, float *C, int64_t ldc, float *slab,
+                   bool keep_slabs, int *splits_out, hipStream_t st) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias;
+  g.M = M; g.N = N; g.K = K;
+  bool big = gemm_use_big_tile(M, N);
+  g.splits = gemm_pick_splits(M, N, K, &g.kps, big);
+  g.slab = slab;
+  g.slab_stride = (int64_t)M * N;
+  if (keep_slabs && g.splits == 1) {  // consumer reads "1 slab" = C itself, bias added by consumer
+    g.bias = nullptr;
+  }
+  int rc = launch_gemm_f32(g, a_km, b_km, st);
+  if (rc) return rc;
+  if (g.splits > 1 && !keep_slabs) {
+    int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, slab,
+                       g.splits, g.slab_stride, n, bias, N, C, ldc);
+    STDADK_CHECK_LAUNCH("slab_sum");
+  }
+  if (splits_out) *splits_out = g.splits;
+  return 0;
+}
+
+
+size_t gemm_slab_floats(int M, int N, int K) {
+  int kps;
+  bool big = gemm_use_big_tile(M, N);
+  int s = gemm_pick_splits(M, N, K, &kps, big);
+  return s > 1 ? (size_t)s * M * N : 0;
+}
+
+}  // namespace stdadk
+
+using namespace stdadk;
+
+extern "C" size_t stdadk_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return align_up(gemm_slab_floats(M, N, K) * sizeof(float), 256);
+}
+
+extern "C" int stdadk_gemm_f32(const float *A, int64_t lda, int32_t a_km, const float *B, int64_t ldb,
+                               int32_t b_km, int32_t M, int32_t N, int32_t K, const float *bias, float *C,
+                               int64_t ldc, void *workspace, size_t workspace_bytes,
+                               stdadk_stream_t stream) {
+  STDADK_REQUIRE(M >= 0 && N >= 0 && K >= 0, STDADK_E_ARG, "gemm: negative size");
+  if (M == 0 || N == 0) return 0;
+  STDADK_REQUIRE(A && B && C, STDADK_E_ARG, "gemm: NULL pointer");
+  STDADK_REQUIRE(!(a_km && !b_km), STDADK_E_ARG, "gemm: layout (a_km, !b_km) not built");
+  STDADK_REQUIRE(ldc >= N, STDADK_E_SHAPE, "gemm: ldc < N");
+  size_t need = gemm_slab_floats(M, N, K) * sizeof(float);
+  STDADK_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), STDADK_E_WORKSPACE,
+                 "gemm: workspace %zu < %zu bytes", workspace_bytes, need);
+  return gemm_run(A, lda, a_km != 0, B, ldb, b_km != 0, M, N, K, bias, C, ldc, (float *)workspace, false,
+                  nullptr, (hipStream_t)stream);
+}

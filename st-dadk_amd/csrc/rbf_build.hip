@@ -1,0 +1,186 @@
+// A2-A5: materialising feature builder  out[b,:] = [ X | phi(coords) | psi(t) ]   (HBM-write bound)
+//
+// Replaces SpatialBasisEmbedding.forward/_wendland/_gaussian/_triangular
+// (stnf/models/st_interp.py:433-491), TemporalBasisEmbedding.forward (:583-596) and the feature
+// concat of STInterpMLP.forward (:843-846).
+//
+// Layout: one workgroup = 256 threads owns a tile of TILE_C = 1024 output columns and walks
+// ROWS_PER_WG observation rows.  A thread keeps its 4 knots (cx, cy, 1/(bw*cal)) in registers for
+// the whole walk, the observation (x, y, t) of the current row is wave-uniform (scalar loads), and
+// every row costs each wave ONE 1-KiB contiguous store (float4 per lane), i.e. a workgroup writes
+// 4 KiB contiguous per row.  Algorithmic bytes: 12 B read + 4*(p+Ks+Kt) B written per observation.
+#include "common.h"
+
+namespace stdadk {
+
+constexpr int TILE_C = 1024;
+constexpr int RB_THREADS = 256;
+
+template <int BASIS>
+__device__ __forceinline__ float basis_eval(float r) {
+  if (BASIS == STDADK_BASIS_WENDLAND) {
+    // (1-r)^6_+ (35 r^2 + 18 r + 3)/3, r clamped to <= 1 (st_interp.py:470-471)
+    r = fminf(r, 1.0f);
+    float om = 1.0f - r;
+    float om2 = om * om;
+    float om6 = om2 * om2 * om2;
+    float poly = fmaf(fmaf(35.0f, r, 18.0f), r, 3.0f);
+    return om6 * poly * (1.0f / 3.0f);
+  } else if (BASIS == STDADK_BASIS_GAUSSIAN) {
+    return __expf(-0.5f * r * r);   // st_interp.py:481
+  } else {
+    return fmaxf(1.0f - r, 0.0f);   // st_interp.py:491
+  }
+}
+
+// kinds of an output column
+enum { COL_X = 0, COL_S = 1, COL_T = 2, COL_PAD = 3 };
+
+template <int VEC, int BASIS, bool ALL_SPATIAL>
+__global__ __launch_bounds__(RB_THREADS) void rbf_build_kernel(
+    const float *__restrict__ coords, const float *__restrict__ t, const float *__restrict__ X,
+    int64_t B, int p, const float *__restrict__ s_centers, const float *__restrict__ s_bw,
+    int64_t Ks, float cal, const float *__restrict__ t_centers, const float *__restrict__ t_bw,
+    int64_t Kt, float *__restrict__ out, int64_t ld_out, int rows_per_wg, int64_t col_tile0) {
+  const int tid = threadIdx.x;
+  const int64_t tile_c0 = (col_tile0 + blockIdx.x) * (int64_t)TILE_C;
+  const int64_t row0 = (int64_t)blockIdx.y * rows_per_wg;
+  const int64_t row1 = min(row0 + (int64_t)rows_per_wg, B);
+  const int64_t D = (int64_t)p + Ks + Kt;
+
+  // this thread's 4 columns: VEC==4 -> 4 consecutive (one float4 store); VEC==1 -> strided by 256
+  int64_t col[4];
+  float c0[4], c1[4], sc[4];
+  int kind[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    col[j] = (VEC == 4) ? tile_c0 + 4 * tid + j : tile_c0 + tid + (int64_t)RB_THREADS * j;
+    int64_t c = col[j];
+    c0[j] = 0.f; c1[j] = 0.f; sc[j] = 0.f;
+    if (ALL_SPATIAL || (c >= p && c < p + Ks)) {
+      kind[j] = COL_S;
+      int64_t k = c - p;
+      c0[j] = s_centers[2 * k];
+      c1[j] = s_centers[2 * k + 1];
+      sc[j] = 1.0f / (s_bw[k] * cal);           // r = dist / (bw*cal), st_interp.py:447-448
+    } else if (c < p) {
+      kind[j] = COL_X;
+    } else if (c < D) {
+      kind[j] = COL_T;
+      int64_t k = c - p - Ks;
+      c0[j] = t_centers[k];
+      sc[j] = t_bw[k];
+    } else {
+      kind[j] = COL_PAD;
+    }
+  }
+
+  for (int64_t b = row0; b < row1; ++b) {
+    const float x = coords[2 * b], y = coords[2 * b + 1];
+    float v[4];
+    if (ALL_SPATIAL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float dx = x - c0[j], dy = y - c1[j];
+        float d = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+        v[j] = basis_eval<BASIS>(d * sc[j]);
+      }
+    } else {
+      const float tt = (Kt > 0) ? t[b] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kind[j] == COL_S) {
+          float dx = x - c0[j], dy = y - c1[j];
+          float d = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+          v[j] = basis_eval<BASIS>(d * sc[j]);
+        } else if (kind[j] == COL_T) {
+          float s = (tt - c0[j]) / sc[j];         // st_interp.py:590-594
+          v[j] = expf(-0.5f * s * s);
+        } else if (kind[j] == COL_X) {
+          v[j] = X[b * p + col[j]];
+        } else {
+          v[j] = 0.f;
+        }
+      }
+    }
+    float *orow = out + b * ld_out;
+    if (VEC == 4) {
+      if (ALL_SPATIAL || col[3] < ld_out) {
+        *reinterpret_cast<float4 *>(orow + col[0]) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col[j] < ld_out) orow[col[j]] = v[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (col[j] < ld_out) orow[col[j]] = v[j];
+    }
+  }
+}
+
+template <int VEC, int BASIS>
+static void launch_rbf(const float *coords, const float *t, const float *X, int64_t B, int p,
+                       const float *s_centers, const float *s_bw, int64_t Ks, float cal,
+                       const float *t_centers, const float *t_bw, int64_t Kt, float *out,
+                       int64_t ld_out, hipStream_t st) {
+  const int64_t n_tiles = ceil_div(ld_out, TILE_C);
+  // column tiles [sp0, sp1) lie entirely inside the spatial block [p, p+Ks)
+  int64_t sp0 = ceil_div(p, TILE_C), sp1 = (p + Ks) / TILE_C;
+  if (sp1 < sp0) sp1 = sp0;
+  // rows per workgroup: enough workgroups to fill 256 CUs x 8, at least 16 rows each
+  int rows = 64;
+  while (rows > 16 && ceil_div(B, rows) * n_tiles < 2048) rows >>= 1;
+  const unsigned gy = (unsigned)ceil_div(B, rows);
+  auto go = [&](int64_t t0, int64_t t1, bool all_sp) {
+    if (t1 <= t0) return;
+    dim3 grid((unsigned)(t1 - t0), gy);
+    if (all_sp)
+      hipLaunchKernelGGL((rbf_build_kernel<VEC, BASIS, true>), grid, dim3(RB_THREADS), 0, st,
+                         coords, t, X, B, p, s_centers, s_bw, Ks, cal, t_centers, t_bw, Kt, out,
+                         ld_out, rows, t0);
+    else
+      hipLaunchKernelGGL((rbf_build_kernel<VEC, BASIS, false>), grid, dim3(RB_THREADS), 0, st,
+                         coords, t, X, B, p, s_centers, s_bw, Ks, cal, t_centers, t_bw, Kt, out,
+                         ld_out, rows, t0);
+  };
+  go(0, sp0 < n_tiles ? sp0 : n_tiles, false);
+  go(sp0, sp1 < n_tiles ? sp1 : n_tiles, true);
+  go(sp1 > sp0 ? sp1 : sp0, n_tiles, false);
+}
+
+}  // namespace stdadk
+
+using namespace stdadk;
+
+extern "C" int stdadk_rbf_build_f32(const float *coords, const float *t, const float *X, int64_t B,
+                                    int32_t p, const float *s_centers, const float *s_bw,
+                                    int64_t Ks, int32_t basis, const float *t_centers,
+                                    const float *t_bw, int64_t Kt, float *out, int64_t ld_out,
+                                    stdadk_stream_t stream) {
+  STDADK_REQUIRE(B >= 0 && p >= 0 && Ks >= 0 && Kt >= 0, STDADK_E_ARG, "rbf_build: negative size");
+  STDADK_REQUIRE(basis >= 0 && basis <= 2, STDADK_E_ARG, "rbf_build: unknown basis %d", basis);
+  STDADK_REQUIRE(ld_out >= p + Ks + Kt, STDADK_E_SHAPE, "rbf_build: ld_out %lld < p+Ks+Kt %lld",
+                 (long long)ld_out, (long long)(p + Ks + Kt));
+  if (B == 0 || ld_out == 0) return 0;
+  STDADK_REQUIRE(out != nullptr, STDADK_E_ARG, "rbf_build: out is NULL");
+  STDADK_REQUIRE(Ks == 0 || (coords && s_centers && s_bw), STDADK_E_ARG,
+                 "rbf_build: spatial inputs NULL");
+  STDADK_REQUIRE(Kt == 0 || (t && t_centers && t_bw), STDADK_E_ARG, "rbf_build: temporal inputs NULL");
+  STDADK_REQUIRE(p == 0 || X, STDADK_E_ARG, "rbf_build: X is NULL with p=%d", p);
+  if (Ks == 0 && !coords) coords = t;  // never dereferenced for a spatial column
+  static const float cals[3] = {1.000000f, 0.223477f, 0.654714f};  // st_interp.py:56-60
+  const float cal = cals[basis];
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec4 = aligned16(out) && (ld_out % 4 == 0);
+#define GO(V, BS) launch_rbf<V, BS>(coords, t, X, B, p, s_centers, s_bw, Ks, cal, t_centers, t_bw, Kt, out, ld_out, st)
+  if (vec4) {
+    if (basis == 0) GO(4, 0); else if (basis == 1) GO(4, 1); else GO(4, 2);
+  } else {
+    if (basis == 0) GO(1, 0); else if (basis == 1) GO(1, 1); else GO(1, 2);
+  }
+#undef GO
+  STDADK_CHECK_LAUNCH("rbf_build");
+  return 0;
+}

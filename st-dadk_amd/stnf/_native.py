@@ -1,0 +1,229 @@
+"""ctypes binding of libstdadk.so (C ABI: include/stdadk.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing, or a
+tensor is not a contiguous fp32 tensor on a HIP device, the call raises — loudly.
+torch is used here only for device memory and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("STDADK_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libstdadk.so"))
+
+MAX_HIDDEN = 8
+BASIS_KIND = {"wendland": 0, "gaussian": 1, "triangular": 2}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("n_hidden", C.c_int32), ("in_dim", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
+                ("out_dim", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float),
+                ("dropout_p", C.c_float)]
+
+
+class MlpTensors(C.Structure):
+    _fields_ = [("W", C.c_void_p * (MAX_HIDDEN + 1)), ("b", C.c_void_p * (MAX_HIDDEN + 1)),
+                ("ln_g", C.c_void_p * MAX_HIDDEN), ("ln_b", C.c_void_p * MAX_HIDDEN)]
+
+
+_lib = None
+
+_SIGNATURES = {
+    "stdadk_abi_version": (C.c_int, []),
+    "stdadk_last_error": (C.c_char_p, []),
+    "stdadk_rbf_build_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                       C.c_void_p]),
+    "stdadk_mlp_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc), C.c_int64]),
+    "stdadk_mlp_forward_f32": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpTensors), C.c_void_p,
+                                         C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_int32, C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p]),
+    "stdadk_mlp_backward_f32": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpTensors),
+                                          C.POINTER(MlpTensors), C.c_void_p, C.c_int64, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
+                                          C.POINTER(C.c_void_p), C.c_void_p]),
+    "stdadk_mse_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "stdadk_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "stdadk_gemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "stdadk_sumsq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "stdadk_adamw_ema_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_float, C.c_void_p, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float,
+                                       C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+}
+
+
+def lib():
+    """Load libstdadk.so once; raise NativeLibraryError (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"libstdadk.so not found at {LIB_PATH}: build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (st-dadk_amd/csrc/build.sh). "
+                f"This package has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError => the .so is stale
+            fn.restype, fn.argtypes = res, args
+        if handle.stdadk_abi_version() != 1:
+            raise NativeLibraryError("libstdadk.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().stdadk_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def _dev(tensor, name):
+    """Validate a device tensor and return its address."""
+    if tensor is None:
+        return None
+    if not tensor.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on a HIP device (cuda:N), got {tensor.device}; "
+                           f"the MI355X build of stnf has no CPU path")
+    if tensor.dtype != torch.float32 and tensor.dtype != torch.uint8 and tensor.dtype != torch.int32:
+        raise RuntimeError(f"{name}: unsupported dtype {tensor.dtype}")
+    if not tensor.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous")
+    return tensor.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------------------------
+def rbf_build(coords, t, X, s_centers, s_bw, basis, t_centers, t_bw, out):
+    """out[b,:] = [X | phi | psi]; `out` is (B, ld) fp32 with ld >= p+Ks+Kt.  Any of the three
+    column groups may be absent (X None/p==0, s_centers None, t_centers None)."""
+    B = out.shape[0]
+    ld = out.stride(0) if out.dim() == 2 else 0
+    if out.dim() != 2 or out.stride(1) != 1:
+        raise RuntimeError("rbf_build: out must be 2-D with unit column stride")
+    p = 0 if X is None or X.numel() == 0 else X.shape[1]
+    Ks = 0 if s_centers is None else s_centers.shape[0]
+    Kt = 0 if t_centers is None else t_centers.shape[0]
+    if Ks and (coords.shape[0] != B or coords.shape[1] != 2):
+        raise RuntimeError(f"rbf_build: coords must be ({B}, 2), got {tuple(coords.shape)}")
+    if Kt and t.numel() != B:
+        raise RuntimeError(f"rbf_build: t must have {B} elements, got {t.numel()}")
+    if p and X.shape[0] != B:
+        raise RuntimeError("rbf_build: X row count mismatch")
+    if not out.is_cuda:
+        raise RuntimeError("rbf_build: expected tensors on a HIP device; this build has no CPU path")
+    rc = lib().stdadk_rbf_build_f32(
+        _dev(coords, "coords") if Ks else None, _dev(t, "t") if Kt else None,
+        _dev(X, "X") if p else None, B, p,
+        _dev(s_centers, "s_centers") if Ks else None, _dev(s_bw, "s_bw") if Ks else None, Ks,
+        BASIS_KIND[basis], _dev(t_centers, "t_centers") if Kt else None,
+        _dev(t_bw, "t_bw") if Kt else None, Kt, out.data_ptr(), ld, _stream())
+    _check(rc, "stdadk_rbf_build_f32")
+    return out
+
+
+def make_desc(in_dim, hidden, out_dim, layernorm, dropout_p, ln_eps=1e-5):
+    if len(hidden) > MAX_HIDDEN:
+        raise RuntimeError(f"at most {MAX_HIDDEN} hidden layers are supported")
+    d = MlpDesc()
+    d.n_hidden, d.in_dim, d.out_dim = len(hidden), in_dim, out_dim
+    for i, h in enumerate(hidden):
+        d.hidden[i] = h
+    d.layernorm, d.ln_eps, d.dropout_p = int(bool(layernorm)), ln_eps, float(dropout_p)
+    return d
+
+
+def make_tensors(Ws, bs, gs, betas):
+    """Pack per-layer tensors (lists; gs/betas may be None) into the ABI struct."""
+    s = MlpTensors()
+    for i, (w, b) in enumerate(zip(Ws, bs)):
+        s.W[i], s.b[i] = _dev(w, f"W[{i}]"), _dev(b, f"b[{i}]")
+    if gs is not None:
+        for i, (g, be) in enumerate(zip(gs, betas)):
+            s.ln_g[i], s.ln_b[i] = _dev(g, f"ln_g[{i}]"), _dev(be, f"ln_b[{i}]")
+    return s
+
+
+def mlp_workspace_bytes(desc, B):
+    n = lib().stdadk_mlp_workspace_bytes(C.byref(desc), B)
+    if n == 0:
+        raise RuntimeError("stdadk_mlp_workspace_bytes: invalid descriptor")
+    return n
+
+
+def _mask_array(masks):
+    if masks is None:
+        return None
+    arr = (C.c_void_p * MAX_HIDDEN)()
+    for i, m in enumerate(masks):
+        arr[i] = _dev(m, f"drop_mask[{i}]") if m is not None else None
+    return arr
+
+
+def mlp_forward(desc, params, features, B, y_pred, workspace, training, seed=0, masks=None):
+    rc = lib().stdadk_mlp_forward_f32(C.byref(desc), C.byref(params), _dev(features, "features"),
+                                      features.stride(0), B, _dev(y_pred, "y_pred"),
+                                      workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                      int(training), seed, _mask_array(masks), _stream())
+    _check(rc, "stdadk_mlp_forward_f32")
+
+
+def mlp_backward(desc, params, grads, features, B, dY, workspace, seed=0, masks=None):
+    rc = lib().stdadk_mlp_backward_f32(C.byref(desc), C.byref(params), C.byref(grads),
+                                       _dev(features, "features"), features.stride(0), B,
+                                       _dev(dY, "dY"), workspace.data_ptr(),
+                                       workspace.numel() * workspace.element_size(), seed,
+                                       _mask_array(masks), _stream())
+    _check(rc, "stdadk_mlp_backward_f32")
+
+
+def gemm(A, a_km, Bm, b_km, M, N, K, bias=None, out=None, workspace=None):
+    """C[M,N] = Aop Bop (+bias) with the MLP's fp32 MFMA GEMM (layouts: include/stdadk.h)."""
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    need = lib().stdadk_gemm_workspace_bytes(M, N, K)
+    if workspace is None and need:
+        workspace = torch.empty(need // 4, device=A.device, dtype=torch.float32)
+    rc = lib().stdadk_gemm_f32(_dev(A, "A"), A.stride(0), int(a_km), _dev(Bm, "B"), Bm.stride(0),
+                               int(b_km), M, N, K, _dev(bias, "bias"), _dev(out, "C"), out.stride(0),
+                               workspace.data_ptr() if workspace is not None else None,
+                               workspace.numel() * 4 if workspace is not None else 0, _stream())
+    _check(rc, "stdadk_gemm_f32")
+    return out
+
+
+def mse(y_pred, y, grad_scale, dY=None, loss_sum=None):
+    rc = lib().stdadk_mse_f32(_dev(y_pred, "y_pred"), _dev(y, "y"), y_pred.numel(), grad_scale,
+                              _dev(dY, "dY"), _dev(loss_sum, "loss_sum"), _stream())
+    _check(rc, "stdadk_mse_f32")
+
+
+def sumsq(g, out):
+    rc = lib().stdadk_sumsq_f32(_dev(g, "g"), g.numel(), _dev(out, "out"), _stream())
+    _check(rc, "stdadk_sumsq_f32")
+
+
+def adamw_ema(p, g, m, v, ema, lr, betas, eps, weight_decay, step, max_norm=0.0, sumsq_buf=None,
+              grad_mul=1.0, ema_decay=0.0, lr_dev=None, step_dev=None):
+    rc = lib().stdadk_adamw_ema_f32(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"),
+                                    _dev(ema, "ema"), p.numel(), lr, _dev(lr_dev, "lr_dev"),
+                                    betas[0], betas[1], eps, weight_decay, int(step),
+                                    _dev(step_dev, "step_dev"), max_norm, _dev(sumsq_buf, "sumsq"),
+                                    grad_mul, ema_decay, _stream())
+    _check(rc, "stdadk_adamw_ema_f32")

@@ -1,0 +1,215 @@
+"""Fused train / inference steps over libstdadk — the fast path behind the drop-in model class.
+
+The reference's batch body (scripts/train_st_interp.py:608-721) is: H2D copies, zero_grad, forward,
+MSELoss, backward, clip_grad_norm_, AdamW.step, EMA.update, two loss.item() syncs.  `TrainStep`
+runs the same arithmetic as one chain of HIP kernels on one stream with
+
+  * parameters, gradients, Adam moments and the EMA shadow in FLAT fp32 buffers (the nn.Module's
+    parameters become views of the flat buffer, so state_dict()/checkpoints are unchanged);
+  * the loss accumulated on the device (no per-step .item());
+  * optional hipGraph capture of the whole step (static input buffers), replayed per batch;
+  * observation-sharded data parallelism: one RCCL all-reduce of the flat gradient per step,
+    count-weighted so a ragged last batch still equals the global-batch mean
+    (SURVEY.md §7 "DDP equivalence"), with the clip norm taken after the reduction.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+
+
+def flatten_parameters(model):
+    """Move every trainable parameter of `model` into one flat fp32 buffer (views keep the
+    original shapes/names).  Each parameter is padded to a multiple of 4 floats so every view
+    is 16-byte aligned.  Returns (flat, [(name, offset, numel)])."""
+    params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    dev = params[0][1].device
+    offs, total = [], 0
+    for n, p in params:
+        offs.append((n, total, p.numel()))
+        total += (p.numel() + 3) // 4 * 4
+    flat = torch.zeros(total, device=dev, dtype=torch.float32)
+    for (n, p), (_, o, k) in zip(params, offs):
+        flat[o:o + k].copy_(p.data.reshape(-1))
+        p.data = flat[o:o + k].view(p.shape)
+    return flat, offs
+
+
+class TrainStep:
+    """One fused optimisation step of STInterpMLP (fixed knots, MSE)."""
+
+    def __init__(self, model, lr=2e-2, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
+                 grad_clip=10.0, ema_decay=None, max_batch=4096, use_graph=False,
+                 process_group=None, distributed=None):
+        self.model = model
+        self.dev = next(model.parameters()).device
+        if self.dev.type != "cuda":
+            raise RuntimeError("TrainStep needs the model on a HIP device; there is no CPU path")
+        self.flat, self.offsets = flatten_parameters(model)
+        self.grad = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.ema = self.flat.clone() if ema_decay is not None else None
+        self.ema_decay = 0.0 if ema_decay is None else float(ema_decay)
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
+        self.grad_clip = float(grad_clip or 0.0)
+        self.step_count = 0
+        self.max_batch = int(max_batch)
+        self.desc = model._native_desc()
+        self.params_t = model._native_tensors()
+        # gradient views in _param_list() order
+        views = []
+        by_name = {n: (o, k) for n, o, k in self.offsets}
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                o, k = by_name[n]
+                views.append(self.grad[o:o + k].view(p.shape))
+        self.grad_views = views
+        self.grads_t = model._pack(views)
+        B = self.max_batch
+        ld = (model.input_dim + 31) // 32 * 32
+        self.feats = torch.zeros(B, ld, device=self.dev)
+        self.ws = torch.empty(N.mlp_workspace_bytes(self.desc, B) // 4, device=self.dev)
+        self.y_pred = torch.empty(B, model.output_dim, device=self.dev)
+        self.dY = torch.empty(B, model.output_dim, device=self.dev)
+        self.loss_sum = torch.zeros(1, device=self.dev)       # running sum of squared errors
+        self.sumsq = torch.zeros(1, device=self.dev)
+        self.lr_dev = torch.full((1,), self.lr, device=self.dev)
+        self.step_dev = torch.zeros(1, device=self.dev, dtype=torch.int32)
+        self.rows_seen = 0
+        # distributed
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.distributed = bool(distributed)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        # graph
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        self._g_in = None
+        self._g_B = None
+
+    # ------------------------------------------------------------------------------------
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        self.lr_dev.fill_(self.lr)
+
+    def _enqueue(self, X, coords, t, y, B, global_rows):
+        """All kernels of one step on the current stream (capturable: no sync, no allocation)."""
+        m = self.model
+        feats = self.feats[:B]
+        N.rbf_build(coords, t, X if (m.p > 0 and X is not None and X.numel() > 0) else None,
+                    m.spatial_basis.centers, m.spatial_basis._bandwidths, m.spatial_basis_function,
+                    m.temporal_basis.centers, m.temporal_basis.bandwidths, feats)
+        seed = (0x5DEECE66D * (self.step_count + 1)) & (2 ** 62 - 1)
+        N.mlp_forward(self.desc, self.params_t, feats, B, self.y_pred[:B], self.ws, True, seed)
+        # d(mean over the GLOBAL batch)/dy: each rank scales by 1/global_rows, the all-reduce SUMs
+        N.mse(self.y_pred[:B], y, 1.0 / (global_rows * m.output_dim), self.dY[:B], self.loss_sum)
+        N.mlp_backward(self.desc, self.params_t, self.grads_t, feats, B, self.dY[:B], self.ws, seed)
+        if self.distributed:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.grad_clip > 0:
+            self.sumsq.zero_()
+            N.sumsq(self.grad, self.sumsq)
+        N.adamw_ema(self.flat, self.grad, self.m, self.v, self.ema, self.lr, self.betas, self.eps,
+                    self.wd, self.step_count + 1, max_norm=self.grad_clip, sumsq_buf=self.sumsq,
+                    ema_decay=self.ema_decay, lr_dev=self.lr_dev, step_dev=self.step_dev)
+
+    def step(self, X, coords, t, y, global_rows=None):
+        """One optimisation step on device tensors coords (B,2), t (B,1)/(B,), y (B,Q), X (B,p)|None.
+        `global_rows` = rows of the global batch over all ranks (defaults to B * world)."""
+        B = coords.shape[0]
+        if B > self.max_batch:
+            raise RuntimeError(f"batch {B} > max_batch {self.max_batch}")
+        if global_rows is None:
+            global_rows = B * self.world
+        coords = coords.contiguous().float()
+        t = t.contiguous().float().view(-1)
+        y = y.contiguous().float()
+        if self.use_graph and not self.distributed:
+            self._step_graph(X, coords, t, y, B, global_rows)
+        else:
+            self._enqueue(X, coords, t, y, B, global_rows)
+        self.step_count += 1
+        self.rows_seen += B
+
+    def _step_graph(self, X, coords, t, y, B, global_rows):
+        if self._graph is None or self._g_B != (B, global_rows):
+            p = self.model.p
+            self._g_in = (torch.empty(B, max(p, 1), device=self.dev) if p > 0 else None,
+                          torch.empty(B, 2, device=self.dev), torch.empty(B, device=self.dev),
+                          torch.empty(B, self.model.output_dim, device=self.dev))
+            self._g_B = (B, global_rows)
+            # the captured AdamW reads lr / step from device scalars so a replay advances them
+            self.step_dev.fill_(self.step_count)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue(self._g_in[0], self._g_in[1], self._g_in[2], self._g_in[3], B, global_rows)
+            self._graph = g
+            # capture does not execute: state is untouched
+        gi = self._g_in
+        if gi[0] is not None:
+            gi[0].copy_(X)
+        gi[1].copy_(coords); gi[2].copy_(t); gi[3].copy_(y)
+        self._graph.replay()
+
+    def mean_loss(self, reset=True):
+        """Mean squared error over the rows seen since the last reset (ONE host sync)."""
+        val = self.loss_sum.item() / max(self.rows_seen * self.model.output_dim, 1)
+        if reset:
+            self.loss_sum.zero_()
+            self.rows_seen = 0
+        return val
+
+
+class Predictor:
+    """Dense-grid inference (reference scripts/train_st_interp.py:1091-1107,1232-1248,1378-1409;
+    evaluate_model :884-961): batched feature build + MLP forward into a preallocated output,
+    optionally replayed from a hipGraph per fixed-size chunk."""
+
+    def __init__(self, model, chunk=65536, use_graph=True):
+        self.model = model
+        self.dev = next(model.parameters()).device
+        self.chunk = int(chunk)
+        self.desc = model._native_desc()
+        ld = (model.input_dim + 31) // 32 * 32
+        self.feats = torch.zeros(self.chunk, ld, device=self.dev)
+        self.ws = torch.empty(N.mlp_workspace_bytes(self.desc, self.chunk) // 4, device=self.dev)
+        self.use_graph = use_graph
+        self._graph = None
+        self._in = (torch.empty(self.chunk, 2, device=self.dev), torch.empty(self.chunk, device=self.dev))
+        self._out = torch.empty(self.chunk, model.output_dim, device=self.dev)
+
+    def _enqueue(self, coords, t, out, B):
+        m = self.model
+        N.rbf_build(coords, t, None, m.spatial_basis.centers, m.spatial_basis._bandwidths,
+                    m.spatial_basis_function, m.temporal_basis.centers, m.temporal_basis.bandwidths,
+                    self.feats[:B])
+        N.mlp_forward(self.desc, m._native_tensors(), self.feats[:B], B, out, self.ws, False, 0)
+
+    @torch.no_grad()
+    def predict(self, coords, t):
+        """coords (N,2), t (N,) or (N,1) on the device -> (N,Q)."""
+        if self.model.p != 0:
+            raise RuntimeError("Predictor: covariates (p>0) are not wired into the dense-grid path")
+        n = coords.shape[0]
+        coords = coords.contiguous().float()
+        t = t.contiguous().float().view(-1)
+        out = torch.empty(n, self.model.output_dim, device=self.dev)
+        for s in range(0, n, self.chunk):
+            B = min(self.chunk, n - s)
+            if self.use_graph and B == self.chunk:
+                if self._graph is None:
+                    torch.cuda.synchronize()
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._enqueue(self._in[0], self._in[1], self._out, B)
+                self._in[0].copy_(coords[s:s + B]); self._in[1].copy_(t[s:s + B])
+                self._graph.replay()
+                out[s:s + B].copy_(self._out)
+            else:
+                self._enqueue(coords[s:s + B], t[s:s + B], out[s:s + B], B)
+        return out

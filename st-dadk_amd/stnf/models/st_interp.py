@@ -1,0 +1,316 @@
+"""Spatio-temporal interpolation model — MI355X build.
+
+Drop-in for the reference's stnf/models/st_interp.py on the fixed-knot MSE path: same class
+names, constructor signatures, attribute names, state_dict keys and error behaviour
+(reference st_interp.py:18-150, :549-596, :599-692, :885-919), but forward()/backward() run the
+hand-written HIP kernels of libstdadk.so (feature builder, fp32-MFMA MLP).  There is no CPU
+arithmetic path: tensors must live on a HIP device.
+
+Knot tables are generated on the host with the same torch calls the reference makes
+(torch.linspace + meshgrid 'ij'), so the buffers are bit-identical by construction; only integer
+index arithmetic happens on the device.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _native as N
+
+_SCOPE_MSG = ("is outside the MI355X hot path built so far (fixed uniform knots, mean regression; "
+              "SURVEY.md §8 'next' rows N2/N3)")
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class SpatialBasisEmbedding(nn.Module):
+    """Multi-resolution 2-D radial basis phi(s) over fixed knot grids (reference :18-546)."""
+
+    CALIBRATION_FACTORS = {'wendland': 1.000000, 'gaussian': 0.223477, 'triangular': 0.654714}
+
+    def __init__(self, n_centers: list = [25, 81, 121], learnable: bool = False,
+                 init_method: str = 'uniform', train_coords: np.ndarray = None,
+                 basis_function: str = 'wendland', gradient_damping: bool = False,
+                 damping_threshold: float = 0.3, damping_strength: float = 1.0):
+        super().__init__()
+        self.n_centers = n_centers
+        self.learnable = learnable
+        self.init_method = init_method
+        self.basis_function = basis_function
+        self.gradient_damping = gradient_damping
+        self.damping_threshold = damping_threshold
+        self.damping_strength = damping_strength
+        if basis_function not in self.CALIBRATION_FACTORS:
+            raise ValueError(f"Unknown basis function: {basis_function}. "
+                             f"Choose from {list(self.CALIBRATION_FACTORS.keys())}")
+        if init_method == 'uniform':
+            centers, bandwidths = self._init_uniform()
+        elif init_method in ('gmm', 'random_site', 'kmeans_balanced'):
+            assert train_coords is not None, f"train_coords required for {init_method} initialization"
+            raise NotImplementedError(f"spatial_init_method='{init_method}' {_SCOPE_MSG}")
+        else:
+            raise ValueError(f"Unknown init_method: {init_method}")
+        if learnable:
+            raise NotImplementedError(f"spatial_learnable=True {_SCOPE_MSG}")
+        self.register_buffer('centers', centers)
+        self.register_buffer('_bandwidths', bandwidths)
+        self.k = centers.shape[0]
+        # side length of every level (uniform grids): integer bookkeeping of the window path
+        self.level_sides = [int(math.sqrt(k)) for k in n_centers]
+
+    @property
+    def bandwidths(self):
+        return self._bandwidths
+
+    def _init_uniform(self):
+        """Knot table of reference :152-185: level `side x side` grid, k = ix*side + iy,
+        bandwidth 2.5 x spacing, levels concatenated in list order."""
+        cs, bs = [], []
+        for k in self.n_centers:
+            side = int(math.sqrt(k))
+            assert side * side == k, f"n_centers must be perfect squares, got {k}"
+            lin = torch.linspace(0, 1, side)
+            gx, gy = torch.meshgrid(lin, lin, indexing='ij')
+            cs.append(torch.stack([gx.flatten(), gy.flatten()], dim=-1))
+            spacing = 1.0 / (side - 1) if side > 1 else 1.0
+            bs.append(torch.full((k,), 2.5 * spacing))
+        return torch.cat(cs, dim=0), torch.cat(bs, dim=0)
+
+    def forward(self, coords: torch.Tensor):
+        """coords (N,2) -> phi (N,k) via stdadk_rbf_build_f32 (reference :433-460)."""
+        squeeze = False
+        if coords.dim() == 3:       # the reference accepts (B,N,2); flatten the batch
+            b, n, _ = coords.shape
+            coords, squeeze = coords.reshape(b * n, 2), (b, n)
+        coords = coords.contiguous().float()
+        out = torch.empty(coords.shape[0], self.k, device=coords.device, dtype=torch.float32)
+        N.rbf_build(coords, None, None, self.centers, self._bandwidths, self.basis_function,
+                    None, None, out)
+        return out.view(*squeeze, self.k) if squeeze else out
+
+    def compute_domain_penalty(self, domain_bounds=(0.0, 1.0)):
+        return torch.tensor(0.0, device=self.centers.device)      # fixed knots (reference :507-508)
+
+    def compute_movement_penalty(self):
+        return torch.tensor(0.0, device=self.centers.device)      # fixed knots (reference :537-538)
+
+
+class TemporalBasisEmbedding(nn.Module):
+    """Multi-resolution 1-D Gaussian basis psi(t) (reference :549-596)."""
+
+    def __init__(self, n_centers: list = [10, 15, 45]):
+        super().__init__()
+        self.n_centers = n_centers
+        cs, bs = [], []
+        for n in n_centers:
+            cs.append(torch.linspace(0.0, 1.0, n))
+            bs.append(torch.full((n,), 2.5 * (1.0 / (n - 1) if n > 1 else 1.0)))
+        self.register_buffer('centers', torch.cat(cs))
+        self.register_buffer('bandwidths', torch.cat(bs))
+        self.k_time = self.centers.shape[0]
+
+    def forward(self, t: torch.Tensor):
+        """t (N,1) -> psi (N,k_time) via stdadk_rbf_build_f32 (reference :583-596)."""
+        t = t.contiguous().float().view(-1)
+        out = torch.empty(t.shape[0], self.k_time, device=t.device, dtype=torch.float32)
+        N.rbf_build(None, t, None, None, None, 'wendland', self.centers, self.bandwidths, out)
+        return out
+
+
+class _MlpFunction(torch.autograd.Function):
+    """features -> y_pred through libstdadk; backward fills the parameter gradients.
+    No gradient flows into the features (fixed knots are buffers; reference :106-107)."""
+
+    @staticmethod
+    def forward(ctx, model, features, training, *params):
+        desc, tensors = model._native_desc(), model._native_tensors()
+        B = features.shape[0]
+        y = torch.empty(B, model.output_dim, device=features.device, dtype=torch.float32)
+        ws = torch.empty(N.mlp_workspace_bytes(desc, B) // 4, device=features.device,
+                         dtype=torch.float32)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and model.dropout_p > 0) else 0
+        N.mlp_forward(desc, tensors, features, B, y, ws, training, seed)
+        ctx.model, ctx.desc, ctx.seed, ctx.B = model, desc, seed, B
+        ctx.save_for_backward(features, ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dY):
+        features, ws = ctx.saved_tensors
+        model = ctx.model
+        plist = model._param_list()
+        grads = [torch.empty_like(p) for p in plist]
+        gt = model._pack(grads)
+        N.mlp_backward(ctx.desc, model._native_tensors(), gt, features, ctx.B,
+                       dY.contiguous().float(), ws, ctx.seed)
+        return (None, None, None) + tuple(grads)
+
+
+class STInterpMLP(nn.Module):
+    """[X | phi(s) | psi(t)] -> (Linear -> LayerNorm -> ReLU -> Dropout) x L -> Linear
+    (reference :599-882)."""
+
+    def __init__(self, p: int = 0, k_spatial_centers: list = [25, 81, 121],
+                 k_temporal_centers: list = [10, 15, 45], hidden_dims: list = [256, 256, 128],
+                 dropout: float = 0.1, layernorm: bool = True, spatial_learnable: bool = False,
+                 spatial_init_method: str = 'uniform', spatial_basis_function: str = 'wendland',
+                 train_coords: np.ndarray = None, gradient_damping: bool = False,
+                 damping_threshold: float = 0.3, damping_strength: float = 1.0,
+                 output_dim: int = 1, use_delta_reparameterization: bool = False):
+        super().__init__()
+        self.p = p
+        self.k_spatial_centers = k_spatial_centers
+        self.spatial_init_method = spatial_init_method
+        self.spatial_basis_function = spatial_basis_function
+        self.output_dim = output_dim
+        self.use_delta_reparameterization = use_delta_reparameterization
+        self.spatial_basis = SpatialBasisEmbedding(
+            n_centers=k_spatial_centers, learnable=spatial_learnable,
+            init_method=spatial_init_method, train_coords=train_coords,
+            basis_function=spatial_basis_function, gradient_damping=gradient_damping,
+            damping_threshold=damping_threshold, damping_strength=damping_strength)
+        self.temporal_basis = TemporalBasisEmbedding(n_centers=k_temporal_centers)
+        self.k_spatial = self.spatial_basis.k
+        self.k_temporal = self.temporal_basis.k_time
+        self.hidden_dims = list(hidden_dims)
+        self.layernorm = bool(layernorm)
+        self.dropout_p = float(dropout)
+
+        layers, prev = [], p + self.k_spatial + self.k_temporal
+        self.input_dim = prev
+        for h in hidden_dims:
+            layers.append(nn.Linear(prev, h))
+            if layernorm:
+                layers.append(nn.LayerNorm(h))
+            layers.append(nn.ReLU())
+            if dropout > 0:
+                layers.append(nn.Dropout(dropout))
+            prev = h
+        self.last_hidden_dim = prev
+        if use_delta_reparameterization and output_dim > 1:
+            raise NotImplementedError(f"use_delta_reparameterization=True {_SCOPE_MSG}")
+        layers.append(nn.Linear(prev, self.output_dim))
+        self.mlp = nn.Sequential(*layers)
+        self.mlp_trunk = None
+        self.delta_params = None
+
+    # ---- native plumbing ---------------------------------------------------------------
+    def _linears(self):
+        return [m for m in self.mlp if isinstance(m, nn.Linear)]
+
+    def _lns(self):
+        return [m for m in self.mlp if isinstance(m, nn.LayerNorm)]
+
+    def _param_list(self):
+        """Parameters in nn.Sequential order == order of named_parameters()."""
+        return [p for m in self.mlp for p in m.parameters(recurse=False)]
+
+    def _pack(self, flat_list):
+        """flat list in _param_list() order -> ABI struct."""
+        it = iter(flat_list)
+        Ws, bs, gs, betas = [], [], [], []
+        for m in self.mlp:
+            if isinstance(m, nn.Linear):
+                Ws.append(next(it)); bs.append(next(it))
+            elif isinstance(m, nn.LayerNorm):
+                gs.append(next(it)); betas.append(next(it))
+        return N.make_tensors(Ws, bs, gs if self.layernorm else None, betas if self.layernorm else None)
+
+    def _native_desc(self):
+        return N.make_desc(self.input_dim, self.hidden_dims, self.output_dim, self.layernorm,
+                           self.dropout_p)
+
+    def _native_tensors(self):
+        return self._pack([p.data for p in self._param_list()])
+
+    def build_features(self, X, coords, t, out=None):
+        """[X | phi | psi] into a row-padded (B, ld) buffer (ld multiple of 32 floats = 128 B)."""
+        B = coords.shape[0]
+        ld = _round_up(self.input_dim, 32)
+        if out is None:
+            out = torch.empty(B, ld, device=coords.device, dtype=torch.float32)
+        Xc = None
+        if X is not None and X.numel() > 0 and self.p > 0:
+            Xc = X.contiguous().float()
+        N.rbf_build(coords.contiguous().float(), t.contiguous().float().view(-1), Xc,
+                    self.spatial_basis.centers, self.spatial_basis._bandwidths,
+                    self.spatial_basis_function, self.temporal_basis.centers,
+                    self.temporal_basis.bandwidths, out)
+        return out
+
+    # ---- reference API ------------------------------------------------------------------
+    def compute_domain_penalty(self):
+        return self.spatial_basis.compute_domain_penalty()
+
+    def compute_movement_penalty(self):
+        return self.spatial_basis.compute_movement_penalty()
+
+    def get_delta_parameters(self):
+        return None     # delta head not enabled (reference :720-721)
+
+    def compute_sparsity_penalty(self, penalty_type='element', lambda_l1=0.01, lambda_group=0.01):
+        """L1 / group-lasso penalties on the first layer's basis columns (reference :724-825);
+        host-side torch on the (256, D) weight, differentiable."""
+        if penalty_type not in ['element', 'group', 'sparse_group', 'none']:
+            raise ValueError(f"Unknown penalty_type: {penalty_type}")
+        dev = next(self.parameters()).device
+        if penalty_type == 'none':
+            z = torch.tensor(0.0, device=dev)
+            return {'spatial_penalty': z, 'temporal_penalty': z.clone(), 'total_penalty': z.clone()}
+        w = self.mlp[0].weight
+        blocks = (w[:, self.p:self.p + self.k_spatial],
+                  w[:, self.p + self.k_spatial:self.p + self.k_spatial + self.k_temporal])
+        pens = []
+        for blk in blocks:
+            pen = torch.zeros((), device=dev)
+            if penalty_type in ('group', 'sparse_group'):
+                pen = pen + lambda_group * blk.norm(2, dim=0).sum()
+            if penalty_type in ('element', 'sparse_group'):
+                pen = pen + lambda_l1 * blk.abs().sum()
+            pens.append(pen)
+        return {'spatial_penalty': pens[0], 'temporal_penalty': pens[1],
+                'total_penalty': pens[0] + pens[1]}
+
+    def forward(self, X: torch.Tensor, coords: torch.Tensor, t: torch.Tensor):
+        """X (B,p), coords (B,2), t (B,1) -> y_pred (B,Q)   (reference :827-882)."""
+        if not coords.is_cuda:
+            raise RuntimeError("stnf (MI355X build): forward() needs tensors on a HIP device "
+                               "(config `device: cuda`); there is no CPU path")
+        feats = self.build_features(X, coords, t)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if need_grad:
+            return _MlpFunction.apply(self, feats, self.training, *self._param_list())
+        B = feats.shape[0]
+        desc = self._native_desc()
+        y = torch.empty(B, self.output_dim, device=feats.device, dtype=torch.float32)
+        ws = torch.empty(N.mlp_workspace_bytes(desc, B) // 4, device=feats.device, dtype=torch.float32)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.training and self.dropout_p > 0) else 0
+        N.mlp_forward(desc, self._native_tensors(), feats, B, y, ws, self.training, seed)
+        return y
+
+
+def create_model(config: dict, train_coords: np.ndarray = None) -> STInterpMLP:
+    """Model from the flat config dict (reference :885-919)."""
+    if config.get('regression_type', 'mean') == 'multi-quantile':
+        output_dim = len(config.get('quantile_levels', [0.1, 0.5, 0.9]))
+    else:
+        output_dim = 1
+    return STInterpMLP(
+        p=config.get('p_covariates', 0),
+        k_spatial_centers=config.get('k_spatial_centers', [25, 81, 121]),
+        k_temporal_centers=config.get('k_temporal_centers', [10, 15, 45]),
+        hidden_dims=config.get('hidden_dims', [256, 256, 128]),
+        dropout=config.get('dropout', 0.1),
+        layernorm=config.get('layernorm', True),
+        spatial_learnable=config.get('spatial_learnable', False),
+        spatial_init_method=config.get('spatial_init_method', 'uniform'),
+        spatial_basis_function=config.get('spatial_basis_function', 'wendland'),
+        train_coords=train_coords,
+        gradient_damping=config.get('gradient_damping', False),
+        damping_threshold=config.get('damping_threshold', 0.3),
+        damping_strength=config.get('damping_strength', 1.0),
+        output_dim=output_dim,
+        use_delta_reparameterization=config.get('use_delta_reparameterization', False))

@@ -1,0 +1,47 @@
+"""Exponential moving average of the trainable parameters (reference stnf/utils/ema.py:9-105).
+
+Same public surface (decay, shadow/backup dicts keyed by parameter name, update / apply_shadow /
+restore / state_dict / load_state_dict).  update() is one fused multi-tensor lerp on the device
+instead of a Python loop of three kernels per parameter."""
+import torch
+import torch.nn as nn
+
+
+class ModelEMA:
+    def __init__(self, model: nn.Module, decay: float = 0.999):
+        self.decay = decay
+        self.model = model
+        self.shadow = {n: p.data.clone() for n, p in model.named_parameters() if p.requires_grad}
+        self.backup = {}
+
+    def update(self, model: nn.Module):
+        """shadow = decay*shadow + (1-decay)*param, after optimizer.step()."""
+        with torch.no_grad():
+            names, params = [], []
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    assert n in self.shadow, f"Parameter {n} not in shadow"
+                    names.append(n)
+                    params.append(p.data)
+            shadows = [self.shadow[n] for n in names]
+            # lerp(s, p, 1-d) = s + (1-d)(p-s) = d*s + (1-d)*p
+            torch._foreach_lerp_(shadows, params, 1.0 - self.decay)
+
+    def apply_shadow(self):
+        for n, p in self.model.named_parameters():
+            if p.requires_grad:
+                self.backup[n] = p.data.clone()
+                p.data = self.shadow[n]
+
+    def restore(self):
+        for n, p in self.model.named_parameters():
+            if p.requires_grad:
+                p.data = self.backup[n]
+        self.backup = {}
+
+    def state_dict(self):
+        return {'decay': self.decay, 'shadow': self.shadow}
+
+    def load_state_dict(self, state_dict):
+        self.decay = state_dict['decay']
+        self.shadow = state_dict['shadow']

@@ -1,0 +1,363 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the stnf package) against the oracle and
+the golden vectors of the real reference.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (BASELINE.json north_star: 1e-5 relative fp32; bit-exact for index bookkeeping):
+  phi / psi / features : max-abs error <= 1e-5 * max|.| (= 1e-5, the bases peak at 1) vs float64 truth
+  y_pred               : max-abs error <= 1e-5 * max(1, max|y|)
+  loss                 : relative error <= 1e-5
+  gradients / params   : rel-L2 error <= 1e-5 per tensor (accumulation order differs from MKL)
+and the HIP result must be at least as close to the float64 truth as the reference's own fp32 run
+where that run is limited by cdist's matmul expansion.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden import cases
+from oracle import stdadk_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-5
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def dev():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    return torch.device("cuda:0")
+
+
+def build_model(cfg, dropout=0.0):
+    from stnf.models import STInterpMLP
+    m = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"],
+                    k_temporal_centers=cfg["k_temporal_centers"], hidden_dims=cfg["hidden_dims"],
+                    dropout=dropout, layernorm=cfg["layernorm"], spatial_basis_function=cfg["basis"],
+                    output_dim=cfg["output_dim"])
+    sd = m.state_dict()
+    for k, v in cases.make_state(cfg).items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v.copy())
+    m.load_state_dict(sd)
+    return m.to(dev())
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def check_vs_digest(got, g, prefix, key, seed, tol=TOL):
+    got = np.asarray(got, dtype=np.float64)
+    norm = float(g[f"{prefix}norm64/{key}"])
+    if f"{prefix}64/{key}" in g:
+        ref = g[f"{prefix}64/{key}"]
+        assert got.shape == ref.shape
+        err = np.linalg.norm((got - ref).ravel()) / max(norm, 1e-30)
+        assert err <= tol, (prefix, key, err)
+        return err
+    pos = cases.digest_positions(got.shape, 2048, seed)
+    ref = g[f"{prefix}64s/{key}"]
+    err = np.linalg.norm(got.ravel()[pos] - ref) / max(np.linalg.norm(ref), 1e-30)
+    assert err <= tol, (prefix, key, "samples", err)
+    assert abs(np.linalg.norm(got.ravel()) - norm) <= tol * norm
+    if got.ndim == 2:
+        cs, rs = g[f"{prefix}colsum64/{key}"], g[f"{prefix}rowsum64/{key}"]
+        # sums over a LayerNorm-ed dim cancel to ~0: scale by the tensor norm
+        assert np.abs(got.sum(0) - cs).max() <= tol * norm * 4
+        assert np.abs(got.sum(1) - rs).max() <= tol * norm * 4
+    return err
+
+
+# ------------------------------------------------------------------ feature builder (A2-A5)
+@pytest.mark.parametrize("name", ["tiny9", "tiny9_ln_p3", "default227", "default227_gauss",
+                                  "default227_tri", "c2_b257"])
+def test_rbf_build_matches_truth(name):
+    cfg = cases.MODEL_CASES[name]
+    g = load(name)
+    X, coords, t, y = cases.make_inputs(cfg)
+    m = build_model(cfg)
+    d = dev()
+    Xd, cd, td = (torch.from_numpy(a).to(d) for a in (X, coords, t))
+    # knot buffers as the product built them (torch.linspace on this host)
+    cen = m.spatial_basis.centers.cpu().numpy()
+    bw = m.spatial_basis.bandwidths.cpu().numpy()
+    tc, tb = m.temporal_basis.centers.cpu().numpy(), m.temporal_basis.bandwidths.cpu().numpy()
+    phi_o = orc.spatial_basis(coords, cen, bw, cfg["basis"])
+    psi_o = orc.temporal_basis(t, tc, tb)
+
+    phi = m.spatial_basis(cd).cpu().numpy()            # (B, Ks) contiguous => ld = Ks
+    psi = m.temporal_basis(td).cpu().numpy()
+    assert phi.shape == phi_o.shape and psi.shape == psi_o.shape
+    assert np.abs(phi - phi_o).max() <= TOL
+    assert np.abs(psi - psi_o).max() <= TOL
+    # golden truth of the reference itself (knots generated in the build container)
+    assert np.abs(psi - g["psi64"]).max() <= TOL
+    assert np.abs(phi.astype(np.float64).sum(1) - g["phi_rowsum64"]).max() <= TOL * phi.shape[1] ** 0.5 * 4
+    if "phi64" in g:
+        assert np.abs(phi - g["phi64"]).max() <= TOL
+    else:
+        rc, val = g["phi64_nz_rc"], g["phi64_nz_val"]
+        assert np.abs(phi[rc[:, 0], rc[:, 1]] - val).max() <= TOL
+    # the HIP direct-form distance beats the reference's own fp32 run (cdist expansion) at K > 25
+    if float(g["phi_err32_maxabs"]) > 1e-6:
+        assert np.abs(phi - phi_o).max() <= float(g["phi_err32_maxabs"])
+    # exact zeros outside the support, exact one on a knot (row 0 = (0,0) sits on knot 0)
+    if cfg["basis"] == "wendland":
+        assert np.array_equal(phi == 0, phi_o == 0) or np.abs(phi[(phi == 0) != (phi_o == 0)]).max() < 1e-12
+        assert phi[0, 0] == 1.0
+
+    # A5: padded feature buffer, column order [X | phi | psi], zero padding
+    feats = m.build_features(Xd, cd, td)
+    D = cfg["p"] + phi.shape[1] + psi.shape[1]
+    assert feats.shape[1] % 32 == 0 and feats.shape[1] >= D
+    f = feats.cpu().numpy()
+    p = cfg["p"]
+    if p:
+        assert np.array_equal(f[:, :p], X)
+    assert np.array_equal(f[:, p:p + phi.shape[1]], phi)
+    assert np.array_equal(f[:, p + phi.shape[1]:D], psi)
+    assert not f[:, D:].any()
+
+
+def test_rbf_build_unaligned_and_ragged():
+    """ld not a multiple of 4, odd B, B == 1, empty batch."""
+    from stnf import _native as N
+    d = dev()
+    cen, bw, _ = orc.uniform_knots([25, 81, 121])
+    tc, tb = orc.temporal_knots([10, 15, 45])
+    cend, bwd, tcd, tbd = (torch.from_numpy(a).to(d) for a in (cen, bw, tc, tb))
+    rs = np.random.RandomState(5)
+    for B in (1, 3, 67, 1025):
+        coords = rs.uniform(-0.1, 1.1, (B, 2)).astype(np.float32)
+        t = rs.uniform(0, 1, (B, 1)).astype(np.float32)
+        X = rs.standard_normal((B, 5)).astype(np.float32)
+        ref = np.concatenate([X, orc.spatial_basis(coords, cen, bw), orc.temporal_basis(t, tc, tb)], 1)
+        for ld in (ref.shape[1], ref.shape[1] + 1, ref.shape[1] + 3):
+            buf = torch.full((B, ld), 7.0, device=d)
+            N.rbf_build(torch.from_numpy(coords).to(d), torch.from_numpy(t).to(d).view(-1),
+                        torch.from_numpy(X).to(d), cend, bwd, "wendland", tcd, tbd, buf)
+            got = buf.cpu().numpy()
+            assert np.abs(got[:, :ref.shape[1]] - ref).max() <= TOL
+            assert not got[:, ref.shape[1]:].any()
+    empty = torch.empty(0, 302, device=d)
+    N.rbf_build(torch.empty(0, 2, device=d), torch.empty(0, device=d), torch.empty(0, 5, device=d),
+                cend, bwd, "wendland", tcd, tbd, empty)
+
+
+# ------------------------------------------------------------------ forward / loss / backward
+@pytest.mark.parametrize("name", list(cases.MODEL_CASES))
+def test_forward_backward_matches_reference(name):
+    cfg = cases.MODEL_CASES[name]
+    g = load(name)
+    X, coords, t, y = cases.make_inputs(cfg)
+    d = dev()
+    m = build_model(cfg)
+    m.train()
+    Xd, cd, td, yd = (torch.from_numpy(a).to(d) for a in (X, coords, t, y))
+    yp = m(Xd, cd, td)
+    assert yp.shape == (cfg["B"], cfg["output_dim"])
+    loss = torch.nn.MSELoss()(yp, yd)
+    loss.backward()
+    y_hip = yp.detach().cpu().numpy()
+    scale = max(1.0, float(np.abs(g["y64"]).max()))
+    err_y = np.abs(y_hip - g["y64"]).max()
+    assert err_y <= TOL * scale, err_y
+    assert abs(loss.item() - float(g["loss64"])) <= TOL * max(float(g["loss64"]), 1e-12)
+    # at least as close to the truth as the reference's fp32 run when that run is cdist-limited
+    if float(g["y_err32_maxabs"]) > 1e-5:
+        assert err_y <= float(g["y_err32_maxabs"])
+    for k, p in m.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        check_vs_digest(p.grad.cpu().numpy(), g, "g", k, cfg["seed"] + 7)
+    # eval / no_grad path gives the same numbers (dropout = 0)
+    m.eval()
+    with torch.no_grad():
+        y2 = m(Xd, cd, td)
+    assert torch.equal(y2, yp.detach())
+
+
+def test_forward_determinism_and_shapes():
+    """Mirrors the reference's structural tests (tests/stnf/models/
+    test_st_interp_delta_reparameterization.py:43-55,141-151): output shape (B, output_dim),
+    attributes, two eval forwards identical."""
+    from stnf.models import STInterpMLP
+    d = dev()
+    m = STInterpMLP(p=0, k_spatial_centers=[9], k_temporal_centers=[5], hidden_dims=[32, 16],
+                    dropout=0.0, layernorm=False, output_dim=5).to(d)
+    m.eval()
+    X, c, t = torch.zeros(4, 0, device=d), torch.rand(4, 2, device=d), torch.rand(4, 1, device=d)
+    with torch.no_grad():
+        a, b = m(X, c, t), m(X, c, t)
+    assert a.shape == (4, 5) and torch.equal(a, b) and torch.isfinite(a).all()
+    assert hasattr(m, "mlp") and m.mlp_trunk is None and m.delta_params is None
+    assert m.get_delta_parameters() is None
+    # gradient flows to every parameter
+    m.train()
+    m(X, c, t).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_wide_output_head_uses_gemm():
+    """output_dim > 8 takes the GEMM path of the output layer; compare with the oracle."""
+    cfg = dict(cases.MODEL_CASES["default227"], output_dim=11, B=77, seed=31)
+    X, coords, t, _ = cases.make_inputs(cfg)
+    d = dev()
+    m = build_model(cfg)
+    params = cases.make_state(cfg)
+    rs = np.random.RandomState(3)
+    y = rs.standard_normal((cfg["B"], 11)).astype(np.float32)
+    yp = m(*(torch.from_numpy(a).to(d) for a in (X, coords, t)))
+    torch.nn.MSELoss()(yp, torch.from_numpy(y).to(d)).backward()
+    cen = m.spatial_basis.centers.cpu().numpy(); bw = m.spatial_basis.bandwidths.cpu().numpy()
+    tc = m.temporal_basis.centers.cpu().numpy(); tb = m.temporal_basis.bandwidths.cpu().numpy()
+    feat = orc.features(X, orc.spatial_basis(coords, cen, bw), orc.temporal_basis(t, tc, tb), 0)
+    yo, cache = orc.mlp_forward(feat, params, 3, True)
+    go = orc.mlp_mse_backward(yo, y, cache, params, 3, True)
+    assert np.abs(yp.detach().cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), go[k]) <= TOL, k
+
+
+# ------------------------------------------------------------------ dropout (explicit masks)
+def test_dropout_masks_forward_backward():
+    from stnf import _native as N
+    cfg = dict(cases.MODEL_CASES["default227"], B=96, seed=41)
+    X, coords, t, y = cases.make_inputs(cfg)
+    d = dev()
+    m = build_model(cfg, dropout=0.25)
+    params = cases.make_state(cfg)
+    rs = np.random.RandomState(9)
+    masks = [(rs.uniform(size=(cfg["B"], h)) >= 0.25).astype(np.uint8) for h in cfg["hidden_dims"]]
+    feats = m.build_features(*(torch.from_numpy(a).to(d) for a in (X, coords, t)))
+    desc = m._native_desc()
+    B = cfg["B"]
+    ws = torch.empty(N.mlp_workspace_bytes(desc, B) // 4, device=d)
+    yp = torch.empty(B, 1, device=d)
+    md = [torch.from_numpy(a).to(d) for a in masks]
+    N.mlp_forward(desc, m._native_tensors(), feats, B, yp, ws, True, 123, md)
+    dY = torch.empty(B, 1, device=d)
+    lsum = torch.zeros(1, device=d)
+    N.mse(yp, torch.from_numpy(y).to(d), 1.0 / B, dY, lsum)
+    grads = [torch.empty_like(p) for p in m._param_list()]
+    N.mlp_backward(desc, m._native_tensors(), m._pack(grads), feats, B, dY, ws, 123, md)
+    cen = m.spatial_basis.centers.cpu().numpy(); bw = m.spatial_basis.bandwidths.cpu().numpy()
+    tc = m.temporal_basis.centers.cpu().numpy(); tb = m.temporal_basis.bandwidths.cpu().numpy()
+    feat = orc.features(X, orc.spatial_basis(coords, cen, bw), orc.temporal_basis(t, tc, tb), 0)
+    yo, cache = orc.mlp_forward(feat, params, 3, True, drop_masks=masks, drop_p=0.25)
+    go = orc.mlp_mse_backward(yo, y, cache, params, 3, True)
+    assert np.abs(yp.cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
+    assert abs(lsum.item() / B - orc.mse(yo, y)) <= TOL * orc.mse(yo, y)
+    for (k, _), gt in zip(m.named_parameters(), grads):
+        assert rel_l2(gt.cpu().numpy(), go[k]) <= TOL, k
+    # generated masks: keep-rate ~ 1-p, train != eval, same seed reproduces
+    m.train()
+    a1 = torch.empty(B, 1, device=d); a2 = torch.empty(B, 1, device=d); a3 = torch.empty(B, 1, device=d)
+    N.mlp_forward(desc, m._native_tensors(), feats, B, a1, ws, True, 77)
+    N.mlp_forward(desc, m._native_tensors(), feats, B, a2, ws, True, 77)
+    N.mlp_forward(desc, m._native_tensors(), feats, B, a3, ws, True, 78)
+    assert torch.equal(a1, a2) and not torch.equal(a1, a3)
+
+
+# ------------------------------------------------------------------ optimiser (A9 / G6)
+@pytest.mark.parametrize("name", ["tiny9_ln_p3", "default227", "c2_b257"])
+def test_optimizer_steps_match_reference(name):
+    """OPT['steps'] x (fwd, MSE, bwd, clip, AdamW, EMA) with the native sumsq/adamw_ema kernels on
+    per-parameter tensors, against the float64 golden of torch.optim.AdamW + clip_grad_norm_ +
+    the reference's ModelEMA."""
+    from stnf import _native as N
+    cfg = cases.MODEL_CASES[name]
+    g = load(name)
+    o = cases.OPT
+    d = dev()
+    m = build_model(cfg)
+    m.train()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    plist = list(m.named_parameters())
+    ms = [torch.zeros_like(p) for _, p in plist]
+    vs = [torch.zeros_like(p) for _, p in plist]
+    ema = [p.detach().clone() for _, p in plist]
+    losses = []
+    for step in range(1, o["steps"] + 1):
+        for _, p in plist:
+            p.grad = None
+        loss = torch.nn.MSELoss()(m(X, coords, t), y)
+        loss.backward()
+        losses.append(loss.item())
+        ss = torch.zeros(1, device=d)
+        for _, p in plist:
+            N.sumsq(p.grad, ss)
+        for (_, p), mm, vv, ee in zip(plist, ms, vs, ema):
+            N.adamw_ema(p.data, p.grad, mm, vv, ee, o["lr"], o["betas"], o["eps"], o["weight_decay"],
+                        step, max_norm=o["grad_clip"], sumsq_buf=ss, ema_decay=o["ema_decay"])
+    assert np.abs(np.array(losses) - g["opt_losses64"]).max() <= 5 * TOL * max(1.0, g["opt_losses64"].max())
+    for (k, p), ee in zip(plist, ema):
+        check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=2e-5)
+        check_vs_digest(ee.cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=2e-5)
+
+
+# ------------------------------------------------------------------ bench-size batch vs oracle
+def test_c2_full_batch_against_oracle():
+    """B = 4096 rows of the BASELINE C2 model: whole train step against the float64 oracle."""
+    cfg = dict(cases.MODEL_CASES["c2_b257"], B=4096, seed=99)
+    X, coords, t, y = cases.make_inputs(cfg)
+    d = dev()
+    m = build_model(cfg)
+    m.train()
+    params = cases.make_state(cfg)
+    yp = m(*(torch.from_numpy(a).to(d) for a in (X, coords, t)))
+    loss = torch.nn.MSELoss()(yp, torch.from_numpy(y).to(d))
+    loss.backward()
+    cen = m.spatial_basis.centers.cpu().numpy(); bw = m.spatial_basis.bandwidths.cpu().numpy()
+    tc = m.temporal_basis.centers.cpu().numpy(); tb = m.temporal_basis.bandwidths.cpu().numpy()
+    feat = orc.features(X, orc.spatial_basis(coords, cen, bw), orc.temporal_basis(t, tc, tb), 0)
+    yo, cache = orc.mlp_forward(feat, params, 3, True)
+    go = orc.mlp_mse_backward(yo, y, cache, params, 3, True)
+    assert np.abs(yp.detach().cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
+    assert abs(loss.item() - orc.mse(yo, y)) <= TOL * orc.mse(yo, y)
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), go[k]) <= TOL, k
+
+
+def test_errors_are_loud():
+    from stnf import _native as N
+    from stnf.models import STInterpMLP
+    d = dev()
+    m = STInterpMLP(k_spatial_centers=[9], k_temporal_centers=[5], hidden_dims=[32, 16], dropout=0.0).to(d)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(4, 0), torch.rand(4, 2), torch.rand(4, 1))      # CPU tensors
+    with pytest.raises(RuntimeError):
+        N.rbf_build(torch.rand(4, 2, device=d), None, None, m.spatial_basis.centers,
+                    m.spatial_basis.bandwidths, "wendland", None, None, torch.empty(4, 5, device=d))
+
+
+# ------------------------------------------------------------------ the MFMA GEMM itself
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (33, 65, 17), (257, 256, 297), (64, 10374, 300),
+                                   (300, 128, 10374), (4096, 256, 256), (256, 297, 4099)])
+def test_gemm_f32_layouts(layout, shape):
+    """C = op(A) op(B) + bias for the three operand layouts the MLP uses, ragged / unaligned
+    shapes included, against float64 numpy.  Asymmetric random operands (a symmetric operand would
+    hide a transposed C write)."""
+    from stnf import _native as N
+    M, Nn, K = shape
+    d = dev()
+    rs = np.random.RandomState(M * 7 + Nn * 3 + K)
+    Aop = rs.standard_normal((M, K)).astype(np.float32)
+    Bop = rs.standard_normal((K, Nn)).astype(np.float32)
+    bias = rs.standard_normal(Nn).astype(np.float32)
+    ref = Aop.astype(np.float64) @ Bop.astype(np.float64) + bias
+    a_km = layout == "tn"
+    b_km = layout in ("nn", "tn")
+    A = torch.from_numpy(np.ascontiguousarray(Aop.T if a_km else Aop)).to(d)
+    Bm = torch.from_numpy(np.ascontiguousarray(Bop if b_km else Bop.T)).to(d)
+    out = N.gemm(A, a_km, Bm, b_km, M, Nn, K, bias=torch.from_numpy(bias).to(d))
+    got = out.cpu().numpy()
+    # fp32 fma chain: error ~ 1e-7 * sum|a b| ~ 1e-7 * sqrt(K) here
+    assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.sqrt(K)) * 4
+    assert rel_l2(got, ref) <= 2e-6

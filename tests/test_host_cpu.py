@@ -1,0 +1,187 @@
+"""CPU-side tests: the C-ABI library loads and exports what include/stdadk.h declares, and the
+host logic of the drop-in `stnf` package (knot tables, state_dict layout, config mapping, loader,
+EMA, metrics, error behaviour) matches the reference's surface.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    from stnf import _native as N
+    hdr = open(os.path.join(ROOT, "include", "stdadk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(stdadk_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert os.path.exists(N.LIB_PATH), "libstdadk.so not built (run __graft_entry__.build())"
+    handle = ctypes.CDLL(N.LIB_PATH)
+    for sym in declared:
+        assert hasattr(handle, sym), f"{sym} declared in stdadk.h but not exported"
+    assert declared == set(N.exported_symbols()), declared ^ set(N.exported_symbols())
+    assert N.lib().stdadk_abi_version() == 1
+
+
+def test_abi_struct_layout_matches_header():
+    from stnf import _native as N
+    # stdadk_mlp_desc: int32 n_hidden, in_dim, hidden[8], out_dim, layernorm; float ln_eps, dropout_p
+    assert ctypes.sizeof(N.MlpDesc) == 4 * (2 + 8 + 2 + 2)
+    assert ctypes.sizeof(N.MlpTensors) == 8 * (9 + 9 + 8 + 8)
+    d = N.make_desc(297, [256, 256, 128], 1, True, 0.1)
+    assert N.lib().stdadk_mlp_workspace_bytes(ctypes.byref(d), 4096) > 4096 * (256 + 256 + 128) * 2 * 4
+    bad = N.make_desc(297, [2000], 1, True, 0.0)
+    assert N.lib().stdadk_mlp_workspace_bytes(ctypes.byref(bad), 16) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from stnf import _native as N
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", "/nonexistent/libstdadk.so")
+    with pytest.raises(N.NativeLibraryError):
+        N.lib()
+
+
+def test_no_cpu_path():
+    from stnf.models import STInterpMLP
+    m = STInterpMLP(k_spatial_centers=[9], k_temporal_centers=[5], hidden_dims=[32, 16], dropout=0.0)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m(torch.zeros(4, 0), torch.rand(4, 2), torch.rand(4, 1))
+    with pytest.raises(RuntimeError):
+        m.spatial_basis(torch.rand(4, 2))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "st-dadk_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("checker", ""), f"{f} mentions the oracle"
+                assert "/root/reference" not in src
+
+
+def test_knot_buffers_bit_exact_with_reference():
+    from stnf.models.st_interp import SpatialBasisEmbedding, TemporalBasisEmbedding
+    g = np.load(os.path.join(GOLD, "knots.npz"))
+    sb = SpatialBasisEmbedding(n_centers=[25, 81, 121])
+    assert np.array_equal(sb.centers.numpy(), g["ml_centers"])
+    assert np.array_equal(sb.bandwidths.numpy(), g["ml_bw"])
+    assert sb.k == 227 and sb.level_sides == [5, 9, 11]
+    for side in (3, 5, 9, 11):
+        s1 = SpatialBasisEmbedding(n_centers=[side * side])
+        assert np.array_equal(s1.centers.numpy(), g[f"s{side}_centers"])
+    tb = TemporalBasisEmbedding(n_centers=[10, 15, 45])
+    assert np.array_equal(tb.centers.numpy(), g["tml_centers"])
+    assert np.array_equal(tb.bandwidths.numpy(), g["tml_bw"])
+    assert tb.k_time == 70
+
+
+def test_constructor_errors_match_reference():
+    from stnf.models.st_interp import SpatialBasisEmbedding
+    with pytest.raises(ValueError):
+        SpatialBasisEmbedding(basis_function="cubic")
+    with pytest.raises(ValueError):
+        SpatialBasisEmbedding(init_method="nope")
+    with pytest.raises(AssertionError):
+        SpatialBasisEmbedding(n_centers=[10])
+    with pytest.raises(AssertionError):
+        SpatialBasisEmbedding(init_method="gmm", train_coords=None)
+
+
+@pytest.mark.parametrize("name", ["tiny9_ln_p3", "default227", "default227_noln", "c2_b257"])
+def test_state_dict_layout(name):
+    """Keys/shapes of SURVEY.md §8(b): buffers + mlp.<i>.{weight,bias} in Sequential order."""
+    from stnf.models import STInterpMLP
+    cfg = cases.MODEL_CASES[name]
+    m = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"],
+                    k_temporal_centers=cfg["k_temporal_centers"], hidden_dims=cfg["hidden_dims"],
+                    dropout=0.0, layernorm=cfg["layernorm"])
+    sd = m.state_dict()
+    Ks, Kt = sum(cfg["k_spatial_centers"]), sum(cfg["k_temporal_centers"])
+    assert tuple(sd["spatial_basis.centers"].shape) == (Ks, 2)
+    assert tuple(sd["spatial_basis._bandwidths"].shape) == (Ks,)
+    assert tuple(sd["temporal_basis.centers"].shape) == (Kt,)
+    assert tuple(sd["temporal_basis.bandwidths"].shape) == (Kt,)
+    expect = {k: shp for k, shp, _ in cases.state_layout(cfg)}
+    got = {k: tuple(v.shape) for k, v in sd.items() if k.startswith("mlp.")}
+    assert got == expect
+    assert [n for n, _ in m.named_parameters()] == list(expect)
+    assert m.k_spatial == Ks and m.k_temporal == Kt and m.p == cfg["p"]
+    assert m.last_hidden_dim == cfg["hidden_dims"][-1] and m.mlp_trunk is None
+
+
+def test_state_dict_with_dropout_shifts_indices():
+    from stnf.models import STInterpMLP
+    m = STInterpMLP(dropout=0.1, layernorm=True)
+    keys = [k for k in m.state_dict() if k.startswith("mlp.") and k.endswith("weight")]
+    assert keys == ["mlp.0.weight", "mlp.1.weight", "mlp.4.weight", "mlp.5.weight", "mlp.8.weight",
+                    "mlp.9.weight", "mlp.12.weight"]
+    assert sum(p.numel() for p in m.parameters()) == 176385        # SURVEY.md §8 "ref default"
+
+
+def test_create_model_config_mapping():
+    from stnf.models import create_model
+    m = create_model({"regression_type": "mean", "k_spatial_centers": [9], "k_temporal_centers": [5],
+                      "hidden_dims": [32, 16], "dropout": 0.0, "layernorm": False, "p_covariates": 2})
+    assert m.output_dim == 1 and m.p == 2 and m.input_dim == 2 + 9 + 5
+    m5 = create_model({"regression_type": "multi-quantile", "quantile_levels": [0.05, 0.25, 0.5, 0.75, 0.95]})
+    assert m5.output_dim == 5 and m5.mlp[-1].out_features == 5
+    with pytest.raises(NotImplementedError):
+        create_model({"spatial_learnable": True})
+
+
+def test_sparsity_penalty_api():
+    from stnf.models import STInterpMLP
+    m = STInterpMLP(k_spatial_centers=[9], k_temporal_centers=[5], hidden_dims=[32, 16], dropout=0.0)
+    w = m.mlp[0].weight.detach()
+    for kind in ("element", "group", "sparse_group", "none"):
+        out = m.compute_sparsity_penalty(kind, lambda_l1=0.3, lambda_group=0.7)
+        assert set(out) == {"spatial_penalty", "temporal_penalty", "total_penalty"}
+        assert float(out["total_penalty"]) >= 0
+    out = m.compute_sparsity_penalty("sparse_group", lambda_l1=0.3, lambda_group=0.7)
+    sp = w[:, :9]
+    expect = 0.7 * sp.norm(2, dim=0).sum() + 0.3 * sp.abs().sum()
+    assert abs(float(out["spatial_penalty"]) - float(expect)) < 1e-5
+    with pytest.raises(ValueError):
+        m.compute_sparsity_penalty("bogus")
+
+
+def test_kaust_loader(tmp_path):
+    from stnf.dataio.kaust_loader import load_kaust_csv_single
+    p = tmp_path / "d.csv"
+    p.write_text("x,y,t,z\n0.5,0.25,1,1.0\n0.1,0.9,1,2.0\n0.5,0.25,2,3.0\n0.7,0.7,3,5.0\n")
+    z, coords, md = load_kaust_csv_single(str(p), normalize=False)
+    assert z.shape == (3, 3) and z.dtype == np.float32 and coords.dtype == np.float32
+    assert np.allclose(coords, [[0.5, 0.25], [0.1, 0.9], [0.7, 0.7]])
+    assert z[0, 0] == 1 and z[0, 1] == 2 and z[1, 0] == 3 and z[2, 2] == 5
+    assert np.isnan(z).sum() == 5 and md == {}
+    zn, _, md = load_kaust_csv_single(str(p), normalize=True)
+    vals = np.array([1, 2, 3, 5], dtype=np.float32)
+    assert abs(md["z_mean"] - vals.mean()) < 1e-6 and abs(md["z_std"] - vals.std()) < 1e-6
+    assert abs(zn[0, 0] - (1 - vals.mean()) / vals.std()) < 1e-6
+
+
+def test_ema_and_metrics_host_logic():
+    from stnf.utils import ModelEMA, compute_metrics, set_seed
+    set_seed(3)
+    lin = torch.nn.Linear(4, 3)
+    ema = ModelEMA(lin, decay=0.9)
+    w0 = lin.weight.data.clone()
+    lin.weight.data += 1.0
+    ema.update(lin)
+    assert torch.allclose(ema.shadow["weight"], 0.9 * w0 + 0.1 * (w0 + 1.0), atol=1e-6)
+    ema.apply_shadow()
+    assert torch.allclose(lin.weight.data, 0.9 * w0 + 0.1 * (w0 + 1.0), atol=1e-6)
+    ema.restore()
+    assert torch.allclose(lin.weight.data, w0 + 1.0)
+    sd = ema.state_dict()
+    assert set(sd) == {"decay", "shadow"}
+    mt = compute_metrics(np.array([1.0, 2.0, np.nan, 4.0]), np.array([1.5, 2.0, 3.0, 3.0]))
+    assert abs(mt["mse"] - (0.25 + 0 + 1) / 3) < 1e-9 and set(mt) == {"rmse", "mae", "r2", "mse"}
