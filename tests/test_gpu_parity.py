@@ -39,11 +39,12 @@ def build_model(cfg, dropout=0.0):
                     k_temporal_centers=cfg["k_temporal_centers"], hidden_dims=cfg["hidden_dims"],
                     dropout=dropout, layernorm=cfg["layernorm"], spatial_basis_function=cfg["basis"],
                     output_dim=cfg["output_dim"])
-    sd = m.state_dict()
-    for k, v in cases.make_state(cfg).items():
-        assert tuple(sd[k].shape) == v.shape, k
-        sd[k] = torch.from_numpy(v.copy())
-    m.load_state_dict(sd)
+    # assign in nn.Sequential order (Dropout layers shift the indices of the state_dict keys)
+    st = cases.make_state(cfg)
+    with torch.no_grad():
+        for (_, p), (k, v) in zip(m.named_parameters(), st.items()):
+            assert tuple(p.shape) == v.shape, k
+            p.copy_(torch.from_numpy(v.copy()))
     return m.to(dev())
 
 
@@ -253,7 +254,7 @@ def test_dropout_masks_forward_backward():
     go = orc.mlp_mse_backward(yo, y, cache, params, 3, True)
     assert np.abs(yp.cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
     assert abs(lsum.item() / B - orc.mse(yo, y)) <= TOL * orc.mse(yo, y)
-    for (k, _), gt in zip(m.named_parameters(), grads):
+    for k, gt in zip(params, grads):
         assert rel_l2(gt.cpu().numpy(), go[k]) <= TOL, k
     # generated masks: keep-rate ~ 1-p, train != eval, same seed reproduces
     m.train()
