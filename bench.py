@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dense", action="store_true", help="force the materialising (dense) kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,7 +130,7 @@ def main():
     batches_per_epoch = max(n_obs // B, 1)
     eng = TrainStep(model, lr=2e-2, weight_decay=5e-4, grad_clip=10.0,
                     ema_decay=1.0 - 1.0 / (10.0 * batches_per_epoch), max_batch=B,
-                    use_graph=(not args.no_graph) and args.dropout == 0.0 and world == 1)
+                    use_graph=(not args.no_graph) and world == 1, force_dense=args.dense)
     perm = torch.randperm(n_obs, device=dev)
 
     def batch(i):
@@ -164,7 +165,7 @@ def main():
         H = wl["hidden_dims"]
         # ---- roofline of the dominant kernels, measured live with HIP events on the launch stream
         c, tt, yy = batch(0)
-        feats = eng.feats[:B]
+        feats = torch.empty(B, (D + 31) // 32 * 32, device=dev)
         t_rbf = time_events(lambda: N.rbf_build(c.contiguous(), tt.contiguous().view(-1), None,
                                                 model.spatial_basis.centers, model.spatial_basis._bandwidths,
                                                 "wendland", model.temporal_basis.centers,
@@ -189,7 +190,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "per_gpu_batch": B, "global_batch": B * args.gpus,
                        "n_obs_per_gpu": n_obs, "dropout": args.dropout, "layernorm": True,
-                       "optimizer": "AdamW lr 2e-2 wd 5e-4 clip 10 + EMA", "path": "materialised features + dense fp32 MFMA MLP",
+                       "optimizer": "AdamW lr 2e-2 wd 5e-4 clip 10 + EMA",
+                       "path": ("index-window layer 1 (compact support) + fp32 MFMA MLP" if eng.uses_window
+                                else "materialised features + dense fp32 MFMA MLP"),
                        "hipgraph": bool(eng.use_graph), "parallelism": f"dp{args.gpus}"},
             "roofline": {"kernel": dom[0], "bound": "mfma", "achieved": dom[2], "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": dom[2] / MFMA_F32_PEAK_TFLOPS, "traffic": None,

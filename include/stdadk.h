@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STDADK_ABI_VERSION 1
+#define STDADK_ABI_VERSION 2
 #define STDADK_MAX_HIDDEN 8
 #define STDADK_MAX_LEVELS 8
 
@@ -134,6 +134,89 @@ int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *em
                          float weight_decay, int32_t step, int32_t *step_dev, float max_norm,
                          const float *sumsq, float grad_mul, float ema_decay,
                          stdadk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step-level entry points: observations in, predictions / gradients out.
+ *
+ * One call = the whole of STInterpMLP.forward (st_interp.py:827-882) [+ nn.MSELoss and
+ * loss.backward(), scripts/train_st_interp.py:617-621,693].  Two interchangeable paths:
+ *   dense  : stdadk_rbf_build_f32 materialises [X|phi|psi] and every layer is a dense MFMA GEMM;
+ *   window : for compact-support bases (Wendland, triangular) on the uniform multi-resolution
+ *            grid of _init_uniform (st_interp.py:152-185) only the <= 6x6 knots per level that can
+ *            be non-zero for an observation are touched: observations are binned into a G x G
+ *            cell grid, layer 0 gathers W0^T rows per observation (fused with LayerNorm/ReLU/
+ *            Dropout) and dW0^T is accumulated by one workgroup per 4x8 knot block.  phi is
+ *            evaluated with the same arithmetic as the dense path; exact zeros are skipped.
+ * The window path needs the first layer's weight (and gradient) stored TRANSPOSED, (in,out)
+ * row-major (flag STDADK_FLAG_W0_T), hidden[0] in {128, 256} and p <= 16; otherwise, or with
+ * STDADK_FLAG_DENSE, the dense path runs (it accepts either W0 layout).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct stdadk_basis_desc {
+  int32_t p;                        /* covariate columns in front of the basis block            */
+  int32_t basis;                    /* STDADK_BASIS_*                                            */
+  int32_t n_levels;                 /* uniform grid levels; 0 = knots are not a uniform grid     */
+  int32_t side[STDADK_MAX_LEVELS];  /* level l is side x side, knot index = ix*side + iy         */
+  int64_t Ks, Kt;                   /* spatial / temporal knot counts                            */
+  const float *s_centers;           /* [Ks,2]  device                                            */
+  const float *s_bw;                /* [Ks]    device                                            */
+  const float *t_centers;           /* [Kt]    device                                            */
+  const float *t_bw;                /* [Kt]    device                                            */
+} stdadk_basis_desc;
+
+#define STDADK_FLAG_DENSE 1 /* force the materialising path                                    */
+#define STDADK_FLAG_W0_T 2  /* params->W[0] and grads->W[0] are (in,out) row-major              */
+
+/* 1 when the (basis, mlp, flags) combination runs the window path, else 0. */
+int32_t stdadk_step_uses_window(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                                int32_t flags);
+size_t stdadk_step_workspace_bytes(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                                   int64_t B, int32_t flags);
+
+/* A2-A6 / A10  forward of one batch: y_pred[B,Q] in the caller's row order.
+ *   training == 0: eval mode (evaluate_model / dense-grid prediction, scripts/train_st_interp.py:
+ *                  884-961,1091-1107,1232-1248,1378-1409): no dropout.
+ *   training != 0: train mode; dropout keep-masks come from drop_seed + step_dev[0] (device int32
+ *                  step counter, may be NULL; a captured graph draws fresh masks per replay), and
+ *                  the workspace keeps what stdadk_backward_f32 needs. */
+int stdadk_forward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                       const stdadk_mlp_tensors *params, const float *coords, const float *t,
+                       const float *X, int64_t B, float *y_pred, void *workspace,
+                       size_t workspace_bytes, int32_t training, uint64_t drop_seed,
+                       const int32_t *step_dev, int32_t flags, stdadk_stream_t stream);
+
+/* A8  loss.backward() (scripts/train_st_interp.py:693) for the batch whose TRAINING forward left
+ * its state in `workspace` (same basis/mlp/B/flags/drop_seed/step_dev): dY[B,Q] = dLoss/dy_pred in
+ * the caller's row order; every parameter gradient is overwritten in `grads`. */
+int stdadk_backward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                        const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads, int64_t B,
+                        const float *dY, void *workspace, size_t workspace_bytes, uint64_t drop_seed,
+                        const int32_t *step_dev, int32_t flags, stdadk_stream_t stream);
+
+/* A2-A8 in one call: training forward, nn.MSELoss and its gradient, backward:
+ *   loss_sum[0] += sum((y_pred-y)^2);  grads = d/dparams of grad_scale * sum((y_pred-y)^2)
+ * (grad_scale = 1/(rows*Q) of the GLOBAL batch, so summing the ranks' gradients gives the global
+ * mean).  y [B,Q]; y_pred [B,Q] is written (caller's row order). */
+int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                             const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,
+                             const float *coords, const float *t, const float *X, const float *y,
+                             int64_t B, float grad_scale, float *loss_sum, float *y_pred,
+                             void *workspace, size_t workspace_bytes, uint64_t drop_seed,
+                             const int32_t *step_dev, int32_t flags, stdadk_stream_t stream);
+
+/* Integer bookkeeping of the window path, exposed for bit-exact tests:
+ *   stdadk_bin_obs_f32: cell key of every observation (cx*G+cy, cx = clamp(floor(x*G),0,G-1)),
+ *     cell_start[G*G+1] (first sorted position of every cell) and perm[B] (sorted position ->
+ *     original index; row-major cells, ascending original index inside a cell).
+ *   stdadk_knot_windows_i32: per observation and level the first knot (ix0, iy0) of the window
+ *     [floor(x*(side-1))-2, +6) clamped into the grid, and its feature column
+ *     col0 = p + level_offset + ix0*side + iy0.  Arrays are [B, n_levels] int32. */
+size_t stdadk_bin_workspace_bytes(int64_t B, int32_t G);
+int stdadk_bin_obs_f32(const float *coords, int64_t B, int32_t G, int32_t *keys,
+                       int32_t *cell_start, int32_t *perm, void *workspace, size_t workspace_bytes,
+                       stdadk_stream_t stream);
+int stdadk_knot_windows_i32(const float *coords, int64_t B, const int32_t *sides_host,
+                            int32_t n_levels, int32_t p, int32_t *ix0, int32_t *iy0, int32_t *col0,
+                            stdadk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * The fp32 MFMA GEMM the Linear layers are built from (nn.Linear forward / autograd backward:

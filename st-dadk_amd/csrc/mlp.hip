@@ -10,33 +10,48 @@
 //       da_prev = dz W               MFMA GEMM (skipped for the first layer: knots are buffers)
 #include "common.h"
 #include "gemm_f32.h"
+#include "window.h"
 
 namespace stdadk {
 
 constexpr int ROW_T = 256;        // threads of the row kernels: 4 waves = 4 rows in flight
 constexpr int MAX_CPL = 16;       // columns per lane => hidden width <= 1024
-constexpr int BWD_ROWS = 16;      // rows per workgroup in the backward row kernel
+
+// rows per workgroup of the backward row kernels: 16 up to B = 8192, then <= 512 workgroups
+static int bwd_rows(int64_t B) {
+  if (B <= 8192) return 16;
+  return (int)(ceil_div(ceil_div(B, 512), 4) * 4);
+}
 
 // ---------------------------------------------------------------------------------------------
-// workspace plan
+// workspace plan (offsets in floats; every sub-buffer starts on a 256-byte boundary)
 // ---------------------------------------------------------------------------------------------
+enum PlanMode { PLAN_MLP = 0, PLAN_STEP_DENSE = 1, PLAN_STEP_WINDOW = 2 };
+
 struct Plan {
   int L;
   int64_t B;
-  size_t xhat[STDADK_MAX_HIDDEN], rstd[STDADK_MAX_HIDDEN], act[STDADK_MAX_HIDDEN];  // float offsets
+  size_t xhat[STDADK_MAX_HIDDEN], rstd[STDADK_MAX_HIDDEN], act[STDADK_MAX_HIDDEN];
   size_t slab, slab_floats;
   size_t dA, dZ;            // [B][hmax] each
   size_t part, part_floats; // column-sum partials
+  // step-level buffers
+  size_t feats; int64_t ldf;           // dense: materialised features
+  size_t psi; int ld_psi;              // window: temporal basis [B][ld_psi]
+  size_t ypred, dY;                    // [B*Q]
+  size_t keys, hist, cursor, cell_start, perm_tmp, perm, xs, ys, ts, y_s, X_s;
+  int G;
   size_t total_floats;
 };
 
-static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p) {
+static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = PLAN_MLP, int p_cov = 0,
+                      int Kt = 0) {
   p->L = d->n_hidden;
   p->B = B;
   size_t off = 0;
   auto take = [&](size_t n) {
     size_t o = off;
-    off += align_up(n, 64);   // 256-byte granules keep every sub-buffer float4-aligned
+    off += align_up(n > 0 ? n : 1, 64);
     return o;
   };
   int hmax = d->out_dim;
@@ -49,26 +64,53 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p) {
     p->act[l] = take((size_t)B * h);
     hmax = h > hmax ? h : hmax;
     size_t s;
-    s = gemm_slab_floats((int)B, h, prev); slab = s > slab ? s : slab;          // forward z
-    s = gemm_slab_floats(h, prev, (int)B); slab = s > slab ? s : slab;          // dW
+    if (!(l == 0 && mode == PLAN_STEP_WINDOW)) {
+      s = gemm_slab_floats((int)B, h, prev); slab = s > slab ? s : slab;          // forward z
+      s = gemm_slab_floats(h, prev, (int)B); slab = s > slab ? s : slab;          // dW  (M=h)
+      s = gemm_slab_floats(prev, h, (int)B); slab = s > slab ? s : slab;          // dW^T (layer 0, W0 transposed)
+    }
     if (l > 0) { s = gemm_slab_floats((int)B, prev, h); slab = s > slab ? s : slab; }  // dA
     prev = h;
   }
-  // the output layer (Q > 8) goes through the GEMM as well
   {
     size_t s = gemm_slab_floats((int)B, d->out_dim, prev); slab = s > slab ? s : slab;
     s = gemm_slab_floats(d->out_dim, prev, (int)B); slab = s > slab ? s : slab;
     s = gemm_slab_floats((int)B, prev, d->out_dim); slab = s > slab ? s : slab;
   }
+  if (mode == PLAN_STEP_WINDOW && d->n_hidden > 0) {
+    size_t s = gemm_slab_floats(Kt, d->hidden[0], (int)B); slab = s > slab ? s : slab;
+    if (p_cov > 0) { s = gemm_slab_floats(p_cov, d->hidden[0], (int)B); slab = s > slab ? s : slab; }
+  }
   p->slab_floats = slab;
   p->slab = take(slab);
   p->dA = take((size_t)B * hmax);
   p->dZ = take((size_t)B * hmax);
-  int64_t nblk = ceil_div(B, BWD_ROWS);
+  int64_t nblk = ceil_div(B, bwd_rows(B));
   p->part_floats = (size_t)nblk * 3 * hmax;
   size_t head = (size_t)nblk * (size_t)d->out_dim * (hmax + 1);
   if (head > p->part_floats) p->part_floats = head;
   p->part = take(p->part_floats);
+  p->feats = p->psi = p->ypred = p->dY = 0;
+  p->ldf = 0; p->ld_psi = 0; p->G = 0;
+  if (mode != PLAN_MLP) {
+    p->ypred = take((size_t)B * d->out_dim);
+    p->dY = take((size_t)B * d->out_dim);
+  }
+  if (mode == PLAN_STEP_DENSE) {
+    p->ldf = (int64_t)align_up((size_t)d->in_dim, 32);
+    p->feats = take((size_t)B * p->ldf);
+  }
+  if (mode == PLAN_STEP_WINDOW) {
+    p->G = pick_cell_grid(B);
+    p->ld_psi = (int)align_up((size_t)(Kt > 0 ? Kt : 1), 4);
+    p->psi = take((size_t)B * p->ld_psi);
+    size_t nc = (size_t)p->G * p->G + 1;
+    p->keys = take(B); p->hist = take(nc); p->cursor = take(nc); p->cell_start = take(nc);
+    p->perm_tmp = take(B); p->perm = take(B);
+    p->xs = take(B); p->ys = take(B); p->ts = take(B);
+    p->y_s = take((size_t)B * d->out_dim);
+    p->X_s = take((size_t)B * (p_cov > 0 ? p_cov : 1));
+  }
   p->total_floats = off;
 }
 
@@ -81,10 +123,11 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_fwd_kernel(
     const float *__restrict__ zsrc, int splits, int64_t slab_stride, const float *__restrict__ bias,
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int64_t B, int h,
     float *__restrict__ xhat, float *__restrict__ rstd_out, float *__restrict__ act, float drop_p,
-    uint64_t seed, int layer, const uint8_t *__restrict__ mask) {
+    uint64_t seed, const int *__restrict__ step_dev, int layer, const uint8_t *__restrict__ mask) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * (ROW_T / 64) + (threadIdx.x >> 6);
   if (row >= B) return;
+  if (step_dev) seed += (uint64_t)step_dev[0] * 0x9E3779B97F4A7C15ULL;
   float z[CPL];
   float sum = 0.f;
 #pragma unroll
@@ -128,7 +171,7 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_fwd_kernel(
   }
 }
 
-// Backward of Dropout -> ReLU -> LayerNorm for BWD_ROWS rows per workgroup (4 rows per wave):
+// Backward of Dropout -> ReLU -> LayerNorm for rows_per_wg rows per workgroup:
 //   du = dA * keep/(1-p) * (u > 0);  dgamma += du*xhat;  dbeta += du
 //   dz = rstd * (dxh - mean(dxh) - xhat*mean(dxh*xhat)),  dxh = du*gamma;   db += dz
 // Column partials go to part[blk][3][h] (dgamma, dbeta, db) and are summed by colsum_kernel.
@@ -136,16 +179,17 @@ template <bool LN, int CPL>
 __global__ __launch_bounds__(ROW_T) void ln_relu_bwd_kernel(
     const float *__restrict__ dA, const float *__restrict__ xhat, const float *__restrict__ rstd,
     const float *__restrict__ gamma, const float *__restrict__ beta, int64_t B, int h,
-    float *__restrict__ dZ, float *__restrict__ part, float drop_p, uint64_t seed, int layer,
-    const uint8_t *__restrict__ mask) {
+    float *__restrict__ dZ, float *__restrict__ part, float drop_p, uint64_t seed,
+    const int *__restrict__ step_dev, int layer, const uint8_t *__restrict__ mask, int rows_per_wg) {
   __shared__ float red[3][ROW_T / 64][256];
+  if (step_dev) seed += (uint64_t)step_dev[0] * 0x9E3779B97F4A7C15ULL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
   float pg[CPL], pb[CPL], pz[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) pg[j] = pb[j] = pz[j] = 0.f;
-  const int64_t row0 = (int64_t)blockIdx.x * BWD_ROWS;
-  for (int rr = wave; rr < BWD_ROWS; rr += ROW_T / 64) {
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_wg;
+  for (int rr = wave; rr < rows_per_wg; rr += ROW_T / 64) {
     const int64_t row = row0 + rr;
     if (row >= B) break;
     float du[CPL], xh[CPL];
@@ -217,21 +261,31 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_bwd_kernel(
   }
 }
 
-// out[c] = sum_blk part[blk*stride + c]  for c < n  (one thread per column, coalesced over c)
-__global__ void colsum_kernel(const float *__restrict__ part, int64_t nblk, int64_t stride, int n,
-                              float *__restrict__ out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int64_t b = 0;
-  for (; b + 3 < nblk; b += 4) {
-    s0 += part[(b + 0) * stride + c];
-    s1 += part[(b + 1) * stride + c];
-    s2 += part[(b + 2) * stride + c];
-    s3 += part[(b + 3) * stride + c];
+// Column sums of per-workgroup partials: out_q[c] = sum_blk part[blk*stride + q*seg + c], q < nseg.
+// 64 columns x 4 block-quarters per workgroup, LDS reduction over the quarters.
+struct ColsumOut { float *o[3]; };
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ part, int64_t nblk,
+                                                     int64_t stride, int seg, int nseg, ColsumOut out) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int n = seg * nseg;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < n) {
+    int64_t b = ty;
+    for (; b + 4 < nblk; b += 8) {
+      s0 += part[b * stride + c];
+      s1 += part[(b + 4) * stride + c];
+    }
+    for (; b < nblk; b += 4) s0 += part[b * stride + c];
   }
-  for (; b < nblk; ++b) s0 += part[b * stride + c];
-  out[c] = (s0 + s1) + (s2 + s3);
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty == 0 && c < n) {
+    float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    int q = c / seg;
+    out.o[q][c - q * seg] = v;
+  }
 }
 
 // Output layer for small Q: y[row][q] = a[row,:] . W[q,:] + b[q].  One wave per row.
@@ -261,17 +315,17 @@ __global__ __launch_bounds__(ROW_T) void head_fwd_kernel(const float *__restrict
   }
 }
 
-// Backward of the small-Q output layer for BWD_ROWS rows per workgroup:
+// Backward of the small-Q output layer for rows_per_wg rows per workgroup:
 //   dA[row][c] = sum_q dY[row][q] W[q][c];  partial dW[q][c] = sum_rows dY[row][q] a[row][c];
 //   partial db[q] = sum_rows dY[row][q].   part[blk][q][h+1] (last column = db).
 __global__ __launch_bounds__(ROW_T) void head_bwd_kernel(const float *__restrict__ a,
                                                          const float *__restrict__ dY, int64_t B,
                                                          int h, const float *__restrict__ W, int Q,
                                                          float *__restrict__ dA,
-                                                         float *__restrict__ part) {
-  const int64_t row0 = (int64_t)blockIdx.x * BWD_ROWS;
-  const int nrow = (int)min((int64_t)BWD_ROWS, B - row0);
-  __shared__ float sdy[BWD_ROWS * HEAD_MAXQ];
+                                                         float *__restrict__ part, int rows_per_wg) {
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int nrow = (int)min((int64_t)rows_per_wg, B - row0);
+  extern __shared__ float sdy[];   // [rows_per_wg][Q]
   for (int i = threadIdx.x; i < nrow * Q; i += ROW_T) sdy[i] = dY[row0 * Q + i];
   __syncthreads();
   float *pbase = part + (int64_t)blockIdx.x * Q * (h + 1);
@@ -298,16 +352,24 @@ __global__ __launch_bounds__(ROW_T) void head_bwd_kernel(const float *__restrict
   }
 }
 
-// split the head partial sums [Q][h+1] into dW[Q][h] and db[Q]
-__global__ void head_reduce_kernel(const float *__restrict__ part, int64_t nblk, int Q, int h,
-                                   float *__restrict__ dW, float *__restrict__ db) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int n = Q * (h + 1);
-  if (i >= n) return;
+// sum the head partials [blk][Q][h+1] and split them into dW[Q][h] and db[Q]
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float *__restrict__ part, int64_t nblk, int Q,
+                                                          int h, float *__restrict__ dW,
+                                                          float *__restrict__ db) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  const int n = Q * (h + 1);
   float s = 0.f;
-  for (int64_t b = 0; b < nblk; ++b) s += part[b * n + i];
-  int q = i / (h + 1), c = i - q * (h + 1);
-  if (c < h) dW[q * h + c] = s; else db[q] = s;
+  if (i < n)
+    for (int64_t b = ty; b < nblk; b += 4) s += part[b * n + i];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n) {
+    float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    int q = i / (h + 1), c = i - q * (h + 1);
+    if (c < h) dW[q * h + c] = v; else db[q] = v;
+  }
 }
 
 __global__ void mse_kernel(const float *__restrict__ yp, const float *__restrict__ y, int64_t n,
@@ -328,6 +390,15 @@ __global__ void mse_kernel(const float *__restrict__ yp, const float *__restrict
   }
 }
 
+// out[i][q] = in[perm[i]][q]
+__global__ void gather_rows_kernel(const float *__restrict__ in, const int *__restrict__ perm, int B, int Q,
+                                   float *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Q) return;
+  int r = i / Q, q = i - r * Q;
+  out[i] = in[(int64_t)perm[r] * Q + q];
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side orchestration
 // ---------------------------------------------------------------------------------------------
@@ -341,6 +412,237 @@ static int check_desc(const stdadk_mlp_desc *d) {
                    "mlp: hidden[%d]=%d unsupported (1..%d)", l, d->hidden[l], 64 * MAX_CPL);
   STDADK_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, STDADK_E_ARG, "mlp: dropout_p out of range");
   return 0;
+}
+
+struct Ctx {
+  const stdadk_mlp_desc *d;
+  const stdadk_mlp_tensors *P;
+  const stdadk_mlp_tensors *G;
+  float *ws;
+  Plan pl;
+  hipStream_t st;
+  int64_t B;
+  bool w0t;             // W[0] / dW[0] stored (in,out)
+  float dp;             // effective dropout probability (0 in eval)
+  uint64_t seed;
+  const int *step_dev;
+  const uint8_t *const *masks;
+};
+
+// hidden layers [l0, L) and the output layer; `in` = input of layer l0
+static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, float *y_pred) {
+  const stdadk_mlp_desc *d = c.d;
+  const stdadk_mlp_tensors *P = c.P;
+  float *ws = c.ws;
+  const Plan &pl = c.pl;
+  const int64_t B = c.B;
+  hipStream_t st = c.st;
+  int rc;
+  for (int l = l0; l < d->n_hidden; ++l) {
+    const int h = d->hidden[l];
+    STDADK_REQUIRE(P->W[l] && P->b[l], STDADK_E_ARG, "mlp_forward: layer %d weights NULL", l);
+    STDADK_REQUIRE(!d->layernorm || (P->ln_g[l] && P->ln_b[l]), STDADK_E_ARG, "mlp_forward: layer %d LN NULL", l);
+    float *xh = ws + pl.xhat[l], *act = ws + pl.act[l];
+    int splits = 1;
+    // z partials: slabs when split, else straight into the xhat buffer (normalised in place below)
+    if (l == 0 && c.w0t)
+      rc = gemm_run(in, ld_in, false, P->W[l], h, true, (int)B, h, K, nullptr, xh, h, ws + pl.slab, true, &splits, st);
+    else
+      rc = gemm_run(in, ld_in, false, P->W[l], K, false, (int)B, h, K, nullptr, xh, h, ws + pl.slab, true, &splits, st);
+    if (rc) return rc;
+    const float *zsrc = splits > 1 ? ws + pl.slab : xh;
+    const uint8_t *mk = (c.masks && c.dp > 0.f) ? c.masks[l] : nullptr;
+    dim3 grid((unsigned)ceil_div(B, ROW_T / 64));
+#define FWD(LN_, CPL_)                                                                                   \
+  hipLaunchKernelGGL((ln_relu_fwd_kernel<LN_, CPL_>), grid, dim3(ROW_T), 0, st, zsrc, splits,            \
+                     (int64_t)B * h, P->b[l], LN_ ? P->ln_g[l] : (const float *)nullptr,                 \
+                     LN_ ? P->ln_b[l] : (const float *)nullptr, d->ln_eps, B, h, xh, ws + pl.rstd[l],    \
+                     act, c.dp, c.seed, c.step_dev, l, mk)
+    if (d->layernorm) { if (h <= 64) FWD(true, 1); else if (h <= 128) FWD(true, 2); else if (h <= 256) FWD(true, 4); else FWD(true, 16); }
+    else { if (h <= 64) FWD(false, 1); else if (h <= 128) FWD(false, 2); else if (h <= 256) FWD(false, 4); else FWD(false, 16); }
+#undef FWD
+    STDADK_CHECK_LAUNCH("ln_relu_fwd");
+    in = act; ld_in = h; K = h;
+  }
+  const int L = d->n_hidden, Q = d->out_dim;
+  STDADK_REQUIRE(P->W[L] && P->b[L], STDADK_E_ARG, "mlp_forward: output layer weights NULL");
+  if (Q <= HEAD_MAXQ && ld_in == K) {
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)ceil_div(B, ROW_T / 64)), dim3(ROW_T), 0, st, in, B,
+                       K, P->W[L], P->b[L], Q, y_pred);
+    STDADK_CHECK_LAUNCH("head_fwd");
+  } else {
+    STDADK_REQUIRE(!(L == 0 && c.w0t), STDADK_E_ARG, "mlp_forward: transposed W0 needs a hidden layer");
+    rc = gemm_run(in, ld_in, false, P->W[L], K, false, (int)B, Q, K, P->b[L], y_pred, Q, ws + pl.slab, false, nullptr, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// Output layer backward, then hidden layers L-1 .. 0.  With `layer0_dense` false the first layer
+// stops after dZ_0 and its bias / LayerNorm gradients (dW0 is produced by the window kernels).
+static int run_backward(Ctx &c, const float *dY, const float *features, int64_t ldf, bool layer0_dense) {
+  const stdadk_mlp_desc *d = c.d;
+  const stdadk_mlp_tensors *P = c.P, *G = c.G;
+  float *ws = c.ws;
+  const Plan &pl = c.pl;
+  const int64_t B = c.B;
+  hipStream_t st = c.st;
+  const int L = d->n_hidden, Q = d->out_dim;
+  const int rows = bwd_rows(B);
+  const int64_t nblk = ceil_div(B, rows);
+  float *dA = ws + pl.dA, *dZ = ws + pl.dZ, *part = ws + pl.part, *slab = ws + pl.slab;
+  int rc;
+
+  const float *aL = L > 0 ? ws + pl.act[L - 1] : features;
+  const int64_t ldaL = L > 0 ? d->hidden[L - 1] : ldf;
+  const int hL = L > 0 ? d->hidden[L - 1] : d->in_dim;
+  STDADK_REQUIRE(G->W[L] && G->b[L], STDADK_E_ARG, "mlp_backward: output layer grads NULL");
+  if (Q <= HEAD_MAXQ && L > 0) {
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)nblk), dim3(ROW_T), sizeof(float) * rows * Q, st, aL, dY,
+                       B, hL, P->W[L], Q, dA, part, rows);
+    STDADK_CHECK_LAUNCH("head_bwd");
+    int n = Q * (hL + 1);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, part, nblk, Q, hL,
+                       G->W[L], G->b[L]);
+    STDADK_CHECK_LAUNCH("head_reduce");
+  } else {
+    // dW_out[Q][hL] = dY^T a ; db = colsum(dY) ; dA = dY W_out
+    rc = gemm_run(dY, Q, true, aL, ldaL, true, Q, hL, (int)B, nullptr, G->W[L], hL, slab, false, nullptr, st);
+    if (rc) return rc;
+    ColsumOut co; co.o[0] = G->b[L]; co.o[1] = co.o[2] = nullptr;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(Q, 64)), dim3(256), 0, st, dY, B, (int64_t)Q, Q, 1, co);
+    STDADK_CHECK_LAUNCH("colsum");
+    if (L > 0) {
+      rc = gemm_run(dY, Q, false, P->W[L], hL, true, (int)B, hL, Q, nullptr, dA, hL, slab, false, nullptr, st);
+      if (rc) return rc;
+    }
+  }
+
+  for (int l = L - 1; l >= 0; --l) {
+    const int h = d->hidden[l];
+    const uint8_t *mk = (c.masks && c.dp > 0.f) ? c.masks[l] : nullptr;
+    STDADK_REQUIRE(G->W[l] && G->b[l], STDADK_E_ARG, "mlp_backward: layer %d grads NULL", l);
+#define BWD(LN_, CPL_)                                                                                   \
+  hipLaunchKernelGGL((ln_relu_bwd_kernel<LN_, CPL_>), dim3((unsigned)nblk), dim3(ROW_T), 0, st, dA,      \
+                     ws + pl.xhat[l], ws + pl.rstd[l], LN_ ? P->ln_g[l] : (const float *)nullptr,        \
+                     LN_ ? P->ln_b[l] : (const float *)nullptr, B, h, dZ, part, c.dp, c.seed,            \
+                     c.step_dev, l, mk, rows)
+    if (d->layernorm) { if (h <= 64) BWD(true, 1); else if (h <= 128) BWD(true, 2); else if (h <= 256) BWD(true, 4); else BWD(true, 16); }
+    else { if (h <= 64) BWD(false, 1); else if (h <= 128) BWD(false, 2); else if (h <= 256) BWD(false, 4); else BWD(false, 16); }
+#undef BWD
+    STDADK_CHECK_LAUNCH("ln_relu_bwd");
+    ColsumOut co;
+    if (d->layernorm) {
+      STDADK_REQUIRE(G->ln_g[l] && G->ln_b[l], STDADK_E_ARG, "mlp_backward: layer %d LN grads NULL", l);
+      co.o[0] = G->ln_g[l]; co.o[1] = G->ln_b[l]; co.o[2] = G->b[l];
+      hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(3 * h, 64)), dim3(256), 0, st, part, nblk,
+                         (int64_t)3 * h, h, 3, co);
+    } else {
+      co.o[0] = G->b[l]; co.o[1] = co.o[2] = nullptr;
+      hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(h, 64)), dim3(256), 0, st, part + 2 * h, nblk,
+                         (int64_t)3 * h, h, 1, co);
+    }
+    STDADK_CHECK_LAUNCH("colsum");
+    if (l == 0 && !layer0_dense) break;
+    const float *ain = l > 0 ? ws + pl.act[l - 1] : features;
+    const int64_t ldin = l > 0 ? d->hidden[l - 1] : ldf;
+    const int kin = l > 0 ? d->hidden[l - 1] : d->in_dim;
+    if (l == 0 && c.w0t)   // dW0^T[kin][h] = ain^T dZ
+      rc = gemm_run(ain, ldin, true, dZ, h, true, kin, h, (int)B, nullptr, G->W[l], h, slab, false, nullptr, st);
+    else                   // dW[h][kin] = dZ^T ain   (reduction over the batch)
+      rc = gemm_run(dZ, h, true, ain, ldin, true, h, kin, (int)B, nullptr, G->W[l], kin, slab, false, nullptr, st);
+    if (rc) return rc;
+    if (l > 0) {
+      // dA_prev[B][kin] = dZ W   (W stored [h][kin] => K-major B operand)
+      rc = gemm_run(dZ, h, false, P->W[l], kin, true, (int)B, kin, h, nullptr, dA, kin, slab, false, nullptr, st);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+static int launch_mse(const float *yp, const float *y, int64_t n, float scale, float *dY, float *loss_sum,
+                      hipStream_t st) {
+  int64_t blocks = ceil_div(n, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, st, yp, y, n, scale, dY, loss_sum);
+  STDADK_CHECK_LAUNCH("mse");
+  return 0;
+}
+
+static int check_basis(const stdadk_basis_desc *b, const stdadk_mlp_desc *d) {
+  STDADK_REQUIRE(b != nullptr, STDADK_E_ARG, "basis desc is NULL");
+  STDADK_REQUIRE(b->p >= 0 && b->Ks >= 0 && b->Kt >= 0 && b->basis >= 0 && b->basis <= 2, STDADK_E_ARG,
+                 "basis desc: bad sizes / kind");
+  STDADK_REQUIRE(b->p + b->Ks + b->Kt == d->in_dim, STDADK_E_SHAPE, "basis desc: p+Ks+Kt=%lld != in_dim=%d",
+                 (long long)(b->p + b->Ks + b->Kt), d->in_dim);
+  STDADK_REQUIRE(b->Ks == 0 || (b->s_centers && b->s_bw), STDADK_E_ARG, "basis desc: spatial knots NULL");
+  STDADK_REQUIRE(b->Kt == 0 || (b->t_centers && b->t_bw), STDADK_E_ARG, "basis desc: temporal knots NULL");
+  if (b->n_levels > 0) {
+    STDADK_REQUIRE(b->n_levels <= STDADK_MAX_LEVELS, STDADK_E_ARG, "basis desc: too many levels");
+    int64_t k = 0;
+    for (int l = 0; l < b->n_levels; ++l) {
+      STDADK_REQUIRE(b->side[l] >= 1, STDADK_E_ARG, "basis desc: side[%d] < 1", l);
+      k += (int64_t)b->side[l] * b->side[l];
+    }
+    STDADK_REQUIRE(k == b->Ks, STDADK_E_SHAPE, "basis desc: sum(side^2)=%lld != Ks=%lld", (long long)k, (long long)b->Ks);
+  }
+  return 0;
+}
+
+static bool want_window(const stdadk_basis_desc *b, const stdadk_mlp_desc *d, int flags) {
+  if (flags & STDADK_FLAG_DENSE) return false;
+  if (!(flags & STDADK_FLAG_W0_T)) return false;
+  if (d->n_hidden < 1 || b->Ks <= 0 || b->Kt <= 0) return false;
+  return l1_window_supported(b->n_levels, b->basis, d->hidden[0], b->p, (int)b->Kt);
+}
+
+static GridView make_grid(const stdadk_basis_desc *b) {
+  static const float cals[3] = {1.000000f, 0.223477f, 0.654714f};   // st_interp.py:56-60
+  GridView g;
+  g.n_levels = b->n_levels;
+  int off = 0;
+  for (int l = 0; l < STDADK_MAX_LEVELS; ++l) {
+    g.side[l] = l < b->n_levels ? b->side[l] : 0;
+    g.off[l] = off;
+    off += g.side[l] * g.side[l];
+  }
+  g.p = b->p; g.Ks = (int)b->Ks; g.Kt = (int)b->Kt;
+  g.cal = cals[b->basis];
+  g.centers = b->s_centers; g.bw = b->s_bw; g.t_centers = b->t_centers; g.t_bw = b->t_bw;
+  return g;
+}
+
+static BinBuffers plan_bins(float *ws, const Plan &pl) {
+  BinBuffers bb;
+  bb.keys = (int *)(ws + pl.keys); bb.hist = (int *)(ws + pl.hist); bb.cursor = (int *)(ws + pl.cursor);
+  bb.cell_start = (int *)(ws + pl.cell_start); bb.perm_tmp = (int *)(ws + pl.perm_tmp);
+  bb.perm = (int *)(ws + pl.perm);
+  bb.xs = ws + pl.xs; bb.ys = ws + pl.ys; bb.ts = ws + pl.ts; bb.y_s = ws + pl.y_s; bb.X_s = ws + pl.X_s;
+  return bb;
+}
+
+// feature build + layer 0 for the window path (sorted order); returns with act[0] ready
+static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float *coords, const float *t,
+                                 const float *X, const float *y) {
+  const Plan &pl = c.pl;
+  BinBuffers bb = plan_bins(c.ws, pl);
+  int rc = bin_obs(coords, t, y, c.d->out_dim, X, b->p, (int)c.B, pl.G, bb, c.st);
+  if (rc) return rc;
+  L1FwdArgs a;
+  a.g = make_grid(b);
+  a.xs = bb.xs; a.ys = bb.ys; a.ts = bb.ts; a.Xs = b->p > 0 ? bb.X_s : nullptr;
+  a.B = (int)c.B; a.H = c.d->hidden[0];
+  a.W0T = c.P->W[0]; a.b0 = c.P->b[0];
+  a.gamma = c.d->layernorm ? c.P->ln_g[0] : nullptr;
+  a.beta = c.d->layernorm ? c.P->ln_b[0] : nullptr;
+  a.eps = c.d->ln_eps;
+  a.xhat = c.ws + pl.xhat[0]; a.rstd = c.ws + pl.rstd[0]; a.act = c.ws + pl.act[0];
+  a.psi = c.ws + pl.psi; a.ld_psi = pl.ld_psi;
+  a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
+  a.rows_per_wg = 0; a.n_wg = 0;
+  STDADK_REQUIRE(a.W0T && a.b0, STDADK_E_ARG, "window forward: layer 0 weights NULL");
+  return l1_window_forward(a, b->basis, c.d->layernorm != 0, c.st);
 }
 
 }  // namespace stdadk
@@ -366,52 +668,14 @@ extern "C" int stdadk_mlp_forward_f32(const stdadk_mlp_desc *d, const stdadk_mlp
   STDADK_REQUIRE(P && features && y_pred && workspace, STDADK_E_ARG, "mlp_forward: NULL pointer");
   STDADK_REQUIRE(ldf >= d->in_dim, STDADK_E_SHAPE, "mlp_forward: ldf %lld < in_dim %d", (long long)ldf, d->in_dim);
   STDADK_REQUIRE(aligned16(workspace), STDADK_E_ALIGN, "mlp_forward: workspace must be 16-byte aligned");
-  Plan pl;
-  make_plan(d, B, &pl);
-  STDADK_REQUIRE(workspace_bytes >= pl.total_floats * sizeof(float), STDADK_E_WORKSPACE,
-                 "mlp_forward: workspace %zu < %zu bytes", workspace_bytes, pl.total_floats * sizeof(float));
-  float *ws = (float *)workspace;
-  hipStream_t st = (hipStream_t)stream;
-  const float dp = training ? d->dropout_p : 0.f;
-
-  const float *in = features;
-  int64_t ld_in = ldf;
-  int K = d->in_dim;
-  for (int l = 0; l < d->n_hidden; ++l) {
-    const int h = d->hidden[l];
-    STDADK_REQUIRE(P->W[l] && P->b[l], STDADK_E_ARG, "mlp_forward: layer %d weights NULL", l);
-    STDADK_REQUIRE(!d->layernorm || (P->ln_g[l] && P->ln_b[l]), STDADK_E_ARG, "mlp_forward: layer %d LN NULL", l);
-    float *xh = ws + pl.xhat[l], *act = ws + pl.act[l];
-    int splits = 1;
-    // z partials: slabs when split, else straight into the xhat buffer (overwritten in place below)
-    rc = gemm_run(in, ld_in, false, P->W[l], K, false, (int)B, h, K, nullptr, xh, h, ws + pl.slab, true, &splits, st);
-    if (rc) return rc;
-    const float *zsrc = splits > 1 ? ws + pl.slab : xh;
-    const uint8_t *mk = (drop_mask && dp > 0.f) ? drop_mask[l] : nullptr;
-    dim3 grid((unsigned)ceil_div(B, ROW_T / 64));
-#define FWD(LN_, CPL_)                                                                                   \
-  hipLaunchKernelGGL((ln_relu_fwd_kernel<LN_, CPL_>), grid, dim3(ROW_T), 0, st, zsrc, splits,            \
-                     (int64_t)B * h, P->b[l], LN_ ? P->ln_g[l] : (const float *)nullptr,                 \
-                     LN_ ? P->ln_b[l] : (const float *)nullptr, d->ln_eps, B, h, xh, ws + pl.rstd[l],    \
-                     act, dp, drop_seed, l, mk)
-    if (d->layernorm) { if (h <= 64) FWD(true, 1); else if (h <= 128) FWD(true, 2); else if (h <= 256) FWD(true, 4); else FWD(true, 16); }
-    else { if (h <= 64) FWD(false, 1); else if (h <= 128) FWD(false, 2); else if (h <= 256) FWD(false, 4); else FWD(false, 16); }
-#undef FWD
-    STDADK_CHECK_LAUNCH("ln_relu_fwd");
-    in = act; ld_in = h; K = h;
-  }
-  const int L = d->n_hidden, Q = d->out_dim;
-  STDADK_REQUIRE(P->W[L] && P->b[L], STDADK_E_ARG, "mlp_forward: output layer weights NULL");
-  if (Q <= HEAD_MAXQ) {
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)ceil_div(B, ROW_T / 64)), dim3(ROW_T), 0, st, in, B,
-                       K, P->W[L], P->b[L], Q, y_pred);
-    STDADK_CHECK_LAUNCH("head_fwd");
-  } else {
-    STDADK_REQUIRE(ld_in == K, STDADK_E_SHAPE, "mlp_forward: unexpected ld");
-    rc = gemm_run(in, ld_in, false, P->W[L], K, false, (int)B, Q, K, P->b[L], y_pred, Q, ws + pl.slab, false, nullptr, st);
-    if (rc) return rc;
-  }
-  return 0;
+  Ctx c;
+  make_plan(d, B, &c.pl);
+  STDADK_REQUIRE(workspace_bytes >= c.pl.total_floats * sizeof(float), STDADK_E_WORKSPACE,
+                 "mlp_forward: workspace %zu < %zu bytes", workspace_bytes, c.pl.total_floats * sizeof(float));
+  c.d = d; c.P = P; c.G = nullptr; c.ws = (float *)workspace; c.st = (hipStream_t)stream; c.B = B;
+  c.w0t = false; c.dp = training ? d->dropout_p : 0.f; c.seed = drop_seed; c.step_dev = nullptr;
+  c.masks = drop_mask;
+  return run_forward(c, 0, features, ldf, d->in_dim, y_pred);
 }
 
 extern "C" int stdadk_mlp_backward_f32(const stdadk_mlp_desc *d, const stdadk_mlp_tensors *P,
@@ -424,73 +688,13 @@ extern "C" int stdadk_mlp_backward_f32(const stdadk_mlp_desc *d, const stdadk_ml
   STDADK_REQUIRE(B > 0 && B < (1ll << 31), STDADK_E_ARG, "mlp_backward: bad B");
   STDADK_REQUIRE(P && G && features && dY && workspace, STDADK_E_ARG, "mlp_backward: NULL pointer");
   STDADK_REQUIRE(ldf >= d->in_dim, STDADK_E_SHAPE, "mlp_backward: ldf < in_dim");
-  Plan pl;
-  make_plan(d, B, &pl);
-  STDADK_REQUIRE(workspace_bytes >= pl.total_floats * sizeof(float), STDADK_E_WORKSPACE,
+  Ctx c;
+  make_plan(d, B, &c.pl);
+  STDADK_REQUIRE(workspace_bytes >= c.pl.total_floats * sizeof(float), STDADK_E_WORKSPACE,
                  "mlp_backward: workspace too small");
-  float *ws = (float *)workspace;
-  hipStream_t st = (hipStream_t)stream;
-  const int L = d->n_hidden, Q = d->out_dim;
-  const float dp = d->dropout_p;
-  const int64_t nblk = ceil_div(B, BWD_ROWS);
-  float *dA = ws + pl.dA, *dZ = ws + pl.dZ, *part = ws + pl.part, *slab = ws + pl.slab;
-
-  // ---- output layer
-  const float *aL = L > 0 ? ws + pl.act[L - 1] : features;
-  const int64_t ldaL = L > 0 ? d->hidden[L - 1] : ldf;
-  const int hL = L > 0 ? d->hidden[L - 1] : d->in_dim;
-  STDADK_REQUIRE(G->W[L] && G->b[L], STDADK_E_ARG, "mlp_backward: output layer grads NULL");
-  if (Q <= HEAD_MAXQ && L > 0) {
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)nblk), dim3(ROW_T), 0, st, aL, dY, B, hL, P->W[L], Q, dA, part);
-    STDADK_CHECK_LAUNCH("head_bwd");
-    int n = Q * (hL + 1);
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, part, nblk, Q, hL, G->W[L], G->b[L]);
-    STDADK_CHECK_LAUNCH("head_reduce");
-  } else {
-    // dW_out[Q][hL] = dY^T a ; db = colsum(dY) ; dA = dY W_out
-    rc = gemm_run(dY, Q, true, aL, ldaL, true, Q, hL, (int)B, nullptr, G->W[L], hL, slab, false, nullptr, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(Q, 256)), dim3(256), 0, st, dY, B, (int64_t)Q, Q, G->b[L]);
-    STDADK_CHECK_LAUNCH("colsum");
-    if (L > 0) {
-      rc = gemm_run(dY, Q, false, P->W[L], hL, true, (int)B, hL, Q, nullptr, dA, hL, slab, false, nullptr, st);
-      if (rc) return rc;
-    }
-  }
-
-  // ---- hidden layers, last to first
-  for (int l = L - 1; l >= 0; --l) {
-    const int h = d->hidden[l];
-    const uint8_t *mk = (drop_mask && dp > 0.f) ? drop_mask[l] : nullptr;
-    STDADK_REQUIRE(G->W[l] && G->b[l], STDADK_E_ARG, "mlp_backward: layer %d grads NULL", l);
-#define BWD(LN_, CPL_)                                                                                   \
-  hipLaunchKernelGGL((ln_relu_bwd_kernel<LN_, CPL_>), dim3((unsigned)nblk), dim3(ROW_T), 0, st, dA,      \
-                     ws + pl.xhat[l], ws + pl.rstd[l], LN_ ? P->ln_g[l] : (const float *)nullptr,        \
-                     LN_ ? P->ln_b[l] : (const float *)nullptr, B, h, dZ, part, dp, drop_seed, l, mk)
-    if (d->layernorm) { if (h <= 64) BWD(true, 1); else if (h <= 128) BWD(true, 2); else if (h <= 256) BWD(true, 4); else BWD(true, 16); }
-    else { if (h <= 64) BWD(false, 1); else if (h <= 128) BWD(false, 2); else if (h <= 256) BWD(false, 4); else BWD(false, 16); }
-#undef BWD
-    STDADK_CHECK_LAUNCH("ln_relu_bwd");
-    dim3 cg((unsigned)ceil_div(h, 256));
-    if (d->layernorm) {
-      hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, st, part, nblk, (int64_t)3 * h, h, G->ln_g[l]);
-      hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, st, part + h, nblk, (int64_t)3 * h, h, G->ln_b[l]);
-    }
-    hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, st, part + 2 * h, nblk, (int64_t)3 * h, h, G->b[l]);
-    STDADK_CHECK_LAUNCH("colsum");
-    const float *ain = l > 0 ? ws + pl.act[l - 1] : features;
-    const int64_t ldin = l > 0 ? d->hidden[l - 1] : ldf;
-    const int kin = l > 0 ? d->hidden[l - 1] : d->in_dim;
-    // dW[h][kin] = dZ^T ain   (reduction over the batch)
-    rc = gemm_run(dZ, h, true, ain, ldin, true, h, kin, (int)B, nullptr, G->W[l], kin, slab, false, nullptr, st);
-    if (rc) return rc;
-    if (l > 0) {
-      // dA_prev[B][kin] = dZ W   (W stored [h][kin] => K-major B operand)
-      rc = gemm_run(dZ, h, false, P->W[l], kin, true, (int)B, kin, h, nullptr, dA, kin, slab, false, nullptr, st);
-      if (rc) return rc;
-    }
-  }
-  return 0;
+  c.d = d; c.P = P; c.G = G; c.ws = (float *)workspace; c.st = (hipStream_t)stream; c.B = B;
+  c.w0t = false; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = nullptr; c.masks = drop_mask;
+  return run_backward(c, dY, features, ldf, true);
 }
 
 extern "C" int stdadk_mse_f32(const float *y_pred, const float *y, int64_t n, float grad_scale,
@@ -498,10 +702,149 @@ extern "C" int stdadk_mse_f32(const float *y_pred, const float *y, int64_t n, fl
   STDADK_REQUIRE(n >= 0, STDADK_E_ARG, "mse: negative n");
   if (n == 0) return 0;
   STDADK_REQUIRE(y_pred && y, STDADK_E_ARG, "mse: NULL pointer");
-  int64_t blocks = ceil_div(n, 256);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y_pred, y, n,
-                     grad_scale, dY, loss_sum);
-  STDADK_CHECK_LAUNCH("mse");
+  return launch_mse(y_pred, y, n, grad_scale, dY, loss_sum, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// step-level entry points: observations in, predictions / gradients out
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t stdadk_step_uses_window(const stdadk_basis_desc *b, const stdadk_mlp_desc *d, int32_t flags) {
+  if (check_desc(d) != 0 || check_basis(b, d) != 0) return 0;
+  return want_window(b, d, flags) ? 1 : 0;
+}
+
+extern "C" size_t stdadk_step_workspace_bytes(const stdadk_basis_desc *b, const stdadk_mlp_desc *d, int64_t B,
+                                              int32_t flags) {
+  if (check_desc(d) != 0 || check_basis(b, d) != 0 || B < 0) return 0;
+  Plan p;
+  make_plan(d, B > 0 ? B : 1, &p, want_window(b, d, flags) ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt);
+  return p.total_floats * sizeof(float);
+}
+
+static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc *d, int64_t B, void *workspace,
+                       size_t workspace_bytes, int32_t flags, bool *window) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  rc = check_basis(b, d);
+  if (rc) return rc;
+  STDADK_REQUIRE(B > 0 && B < (1ll << 31), STDADK_E_ARG, "step: bad B");
+  STDADK_REQUIRE(workspace && aligned16(workspace), STDADK_E_ALIGN, "step: workspace NULL or not 16-byte aligned");
+  *window = want_window(b, d, flags);
+  make_plan(d, B, &c.pl, *window ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt);
+  STDADK_REQUIRE(workspace_bytes >= c.pl.total_floats * sizeof(float), STDADK_E_WORKSPACE,
+                 "step: workspace %zu < %zu bytes", workspace_bytes, c.pl.total_floats * sizeof(float));
+  c.d = d; c.ws = (float *)workspace; c.B = B;
+  c.w0t = (flags & STDADK_FLAG_W0_T) != 0;
+  c.masks = nullptr;
   return 0;
+}
+
+// forward of one batch; training != 0 keeps everything backward needs in the workspace
+static int step_forward(Ctx &c, const stdadk_basis_desc *b, bool window, const float *coords, const float *t,
+                        const float *X, float *y_pred, stdadk_stream_t stream) {
+  const stdadk_mlp_desc *d = c.d;
+  float *ws = c.ws;
+  int rc;
+  if (window) {
+    rc = window_layer0_forward(c, b, coords, t, X, nullptr);
+    if (rc) return rc;
+    rc = run_forward(c, 1, ws + c.pl.act[0], d->hidden[0], d->hidden[0], ws + c.pl.ypred);
+    if (rc) return rc;
+    return unpermute_rows(ws + c.pl.ypred, (const int *)(ws + c.pl.perm), (int)c.B, d->out_dim, y_pred, c.st);
+  }
+  rc = stdadk_rbf_build_f32(coords, t, X, c.B, b->p, b->s_centers, b->s_bw, b->Ks, b->basis, b->t_centers,
+                            b->t_bw, b->Kt, ws + c.pl.feats, c.pl.ldf, stream);
+  if (rc) return rc;
+  return run_forward(c, 0, ws + c.pl.feats, c.pl.ldf, d->in_dim, y_pred);
+}
+
+// backward of the batch whose training forward left its state in the workspace; dY in caller order
+static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const float *dY) {
+  const stdadk_mlp_desc *d = c.d;
+  float *ws = c.ws;
+  int rc;
+  if (!window) return run_backward(c, dY, ws + c.pl.feats, c.pl.ldf, true);
+  const int H = d->hidden[0], Q = d->out_dim;
+  // dY rows into sorted order
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(c.B * Q, 256)), dim3(256), 0, c.st, dY,
+                     (const int *)(ws + c.pl.perm), (int)c.B, Q, ws + c.pl.dY);
+  STDADK_CHECK_LAUNCH("gather_rows");
+  rc = run_backward(c, ws + c.pl.dY, nullptr, 0, false);
+  if (rc) return rc;
+  // dW0^T: spatial rows by the knot-block owners, temporal / covariate rows by small GEMMs
+  STDADK_REQUIRE(c.G->W[0], STDADK_E_ARG, "backward: dW[0] NULL");
+  L1BwdArgs a;
+  a.g = make_grid(b);
+  a.xs = ws + c.pl.xs; a.ys = ws + c.pl.ys;
+  a.cell_start = (const int *)(ws + c.pl.cell_start);
+  a.G = c.pl.G; a.B = (int)c.B; a.H = H;
+  a.dZ = ws + c.pl.dZ; a.dW0T = c.G->W[0];
+  rc = l1_window_backward(a, b->basis, c.st);
+  if (rc) return rc;
+  rc = gemm_run(ws + c.pl.psi, c.pl.ld_psi, true, ws + c.pl.dZ, H, true, (int)b->Kt, H, (int)c.B, nullptr,
+                c.G->W[0] + (size_t)(b->p + b->Ks) * H, H, ws + c.pl.slab, false, nullptr, c.st);
+  if (rc) return rc;
+  if (b->p > 0) {
+    rc = gemm_run(ws + c.pl.X_s, b->p, true, ws + c.pl.dZ, H, true, b->p, H, (int)c.B, nullptr, c.G->W[0], H,
+                  ws + c.pl.slab, false, nullptr, c.st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int stdadk_forward_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                  const stdadk_mlp_tensors *P, const float *coords, const float *t,
+                                  const float *X, int64_t B, float *y_pred, void *workspace,
+                                  size_t workspace_bytes, int32_t training, uint64_t drop_seed,
+                                  const int32_t *step_dev, int32_t flags, stdadk_stream_t stream) {
+  if (B == 0) return 0;
+  Ctx c;
+  bool window;
+  int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
+  if (rc) return rc;
+  STDADK_REQUIRE(P && coords && t && y_pred, STDADK_E_ARG, "forward: NULL pointer");
+  STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "forward: X is NULL with p=%d", b->p);
+  c.P = P; c.G = nullptr; c.st = (hipStream_t)stream;
+  c.dp = training ? d->dropout_p : 0.f; c.seed = drop_seed; c.step_dev = step_dev;
+  return step_forward(c, b, window, coords, t, X, y_pred, stream);
+}
+
+extern "C" int stdadk_backward_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                   const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G, int64_t B,
+                                   const float *dY, void *workspace, size_t workspace_bytes,
+                                   uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
+                                   stdadk_stream_t stream) {
+  if (B == 0) return 0;
+  Ctx c;
+  bool window;
+  int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
+  if (rc) return rc;
+  STDADK_REQUIRE(P && G && dY, STDADK_E_ARG, "backward: NULL pointer");
+  c.P = P; c.G = G; c.st = (hipStream_t)stream; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = step_dev;
+  return step_backward(c, b, window, dY);
+}
+
+extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                        const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
+                                        const float *coords, const float *t, const float *X,
+                                        const float *y, int64_t B, float grad_scale, float *loss_sum,
+                                        float *y_pred, void *workspace, size_t workspace_bytes,
+                                        uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
+                                        stdadk_stream_t stream) {
+  if (B == 0) return 0;
+  Ctx c;
+  bool window;
+  int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
+  if (rc) return rc;
+  STDADK_REQUIRE(P && G && coords && t && y && y_pred, STDADK_E_ARG, "train_fwd_bwd: NULL pointer");
+  STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "train_fwd_bwd: X is NULL with p=%d", b->p);
+  c.P = P; c.G = G; c.st = (hipStream_t)stream; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = step_dev;
+  rc = step_forward(c, b, window, coords, t, X, y_pred, stream);
+  if (rc) return rc;
+  // dY (caller order) lives in the plan's dY buffer for the dense path; the window path gathers it
+  // into that buffer, so stage it in the ypred buffer there (free once y_pred has been un-permuted)
+  float *dY = c.ws + (window ? c.pl.ypred : c.pl.dY);
+  rc = launch_mse(y_pred, y, B * d->out_dim, grad_scale, dY, loss_sum, c.st);
+  if (rc) return rc;
+  return step_backward(c, b, window, dY);
 }

@@ -9,29 +9,12 @@
 // the whole walk, the observation (x, y, t) of the current row is wave-uniform (scalar loads), and
 // every row costs each wave ONE 1-KiB contiguous store (float4 per lane), i.e. a workgroup writes
 // 4 KiB contiguous per row.  Algorithmic bytes: 12 B read + 4*(p+Ks+Kt) B written per observation.
-#include "common.h"
+#include "basis.h"
 
 namespace stdadk {
 
 constexpr int TILE_C = 1024;
 constexpr int RB_THREADS = 256;
-
-template <int BASIS>
-__device__ __forceinline__ float basis_eval(float r) {
-  if (BASIS == STDADK_BASIS_WENDLAND) {
-    // (1-r)^6_+ (35 r^2 + 18 r + 3)/3, r clamped to <= 1 (st_interp.py:470-471)
-    r = fminf(r, 1.0f);
-    float om = 1.0f - r;
-    float om2 = om * om;
-    float om6 = om2 * om2 * om2;
-    float poly = fmaf(fmaf(35.0f, r, 18.0f), r, 3.0f);
-    return om6 * poly * (1.0f / 3.0f);
-  } else if (BASIS == STDADK_BASIS_GAUSSIAN) {
-    return __expf(-0.5f * r * r);   // st_interp.py:481
-  } else {
-    return fmaxf(1.0f - r, 0.0f);   // st_interp.py:491
-  }
-}
 
 // kinds of an output column
 enum { COL_X = 0, COL_S = 1, COL_T = 2, COL_PAD = 3 };
@@ -62,7 +45,7 @@ __global__ __launch_bounds__(RB_THREADS) void rbf_build_kernel(
       int64_t k = c - p;
       c0[j] = s_centers[2 * k];
       c1[j] = s_centers[2 * k + 1];
-      sc[j] = 1.0f / (s_bw[k] * cal);           // r = dist / (bw*cal), st_interp.py:447-448
+      sc[j] = knot_scale(s_bw[k], cal);
     } else if (c < p) {
       kind[j] = COL_X;
     } else if (c < D) {
@@ -76,26 +59,22 @@ __global__ __launch_bounds__(RB_THREADS) void rbf_build_kernel(
   }
 
   for (int64_t b = row0; b < row1; ++b) {
-    const float x = coords[2 * b], y = coords[2 * b + 1];
+    const float x = (ALL_SPATIAL || Ks > 0) ? coords[2 * b] : 0.f;
+    const float y = (ALL_SPATIAL || Ks > 0) ? coords[2 * b + 1] : 0.f;
     float v[4];
     if (ALL_SPATIAL) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float dx = x - c0[j], dy = y - c1[j];
-        float d = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
-        v[j] = basis_eval<BASIS>(d * sc[j]);
+        v[j] = phi_eval<BASIS>(x, y, c0[j], c1[j], sc[j]);
       }
     } else {
       const float tt = (Kt > 0) ? t[b] : 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (kind[j] == COL_S) {
-          float dx = x - c0[j], dy = y - c1[j];
-          float d = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
-          v[j] = basis_eval<BASIS>(d * sc[j]);
+          v[j] = phi_eval<BASIS>(x, y, c0[j], c1[j], sc[j]);
         } else if (kind[j] == COL_T) {
-          float s = (tt - c0[j]) / sc[j];         // st_interp.py:590-594
-          v[j] = expf(-0.5f * s * s);
+          v[j] = psi_eval(tt, c0[j], sc[j]);
         } else if (kind[j] == COL_X) {
           v[j] = X[b * p + col[j]];
         } else {
@@ -169,7 +148,6 @@ extern "C" int stdadk_rbf_build_f32(const float *coords, const float *t, const f
                  "rbf_build: spatial inputs NULL");
   STDADK_REQUIRE(Kt == 0 || (t && t_centers && t_bw), STDADK_E_ARG, "rbf_build: temporal inputs NULL");
   STDADK_REQUIRE(p == 0 || X, STDADK_E_ARG, "rbf_build: X is NULL with p=%d", p);
-  if (Ks == 0 && !coords) coords = t;  // never dereferenced for a spatial column
   static const float cals[3] = {1.000000f, 0.223477f, 0.654714f};  // st_interp.py:56-60
   const float cal = cals[basis];
   hipStream_t st = (hipStream_t)stream;

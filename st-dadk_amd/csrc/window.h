@@ -1,0 +1,81 @@
+// Index-window (compact-support) path of the first layer: observation binning + fused
+// basis -> Linear(+LayerNorm+ReLU+Dropout) forward + owner-computes dW backward.
+#pragma once
+#include "common.h"
+
+namespace stdadk {
+
+constexpr int WIN = 6;          // knots per axis that can lie within 2.5 spacings of a point
+constexpr int WIN_MAX_P = 16;   // covariates handled by the window path
+
+// Device view of the uniform multi-resolution knot grid (A1, stnf/models/st_interp.py:152-185):
+// level l is a side[l] x side[l] grid, knot index off[l] + ix*side + iy.
+struct GridView {
+  int n_levels;
+  int side[STDADK_MAX_LEVELS];
+  int off[STDADK_MAX_LEVELS];
+  int p;                 // feature column of spatial knot 0
+  int Ks, Kt;
+  float cal;             // calibration factor of the basis
+  const float *centers;  // [Ks][2]
+  const float *bw;       // [Ks]
+  const float *t_centers;
+  const float *t_bw;
+};
+
+// Buffers of the observation binning (all device memory, caller-carved).
+struct BinBuffers {
+  int *keys;        // [B]     cell of every observation (original order)
+  int *hist;        // [G*G]   zeroed by bin_obs
+  int *cursor;      // [G*G]
+  int *cell_start;  // [G*G+1] first sorted position of every cell
+  int *perm_tmp;    // [B]
+  int *perm;        // [B]     sorted position -> original index (ascending inside a cell)
+  float *xs, *ys, *ts;  // [B] sorted coordinates / times
+  float *y_s;       // [B*Q]   sorted targets (may be NULL)
+  float *X_s;       // [B*p]   sorted covariates (may be NULL)
+};
+
+int pick_cell_grid(int64_t B);   // G: cells per axis, power of two in [8, 256]
+
+int bin_obs(const float *coords, const float *t, const float *y, int Q, const float *X, int p,
+            int B, int G, const BinBuffers &bb, hipStream_t st);
+
+struct L1FwdArgs {
+  GridView g;
+  const float *xs, *ys, *ts, *Xs;
+  int B, H;
+  const float *W0T;     // [D][H]
+  const float *b0, *gamma, *beta;
+  float eps;
+  float *xhat, *rstd, *act, *psi;
+  int ld_psi;
+  float drop_p;
+  uint64_t seed;
+  const int *step_dev;
+  int rows_per_wg, n_wg;
+};
+
+// z0 = [X|phi|psi] W0 + b0 -> LN -> ReLU -> Dropout for sorted observations; also writes psi.
+int l1_window_forward(const L1FwdArgs &a, int basis, bool layernorm, hipStream_t st);
+bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt);
+
+struct L1BwdArgs {
+  GridView g;
+  const float *xs, *ys;
+  const int *cell_start;
+  int G, B, H;
+  const float *dZ;      // [B][H] sorted order
+  float *dW0T;          // [D][H]
+  int blk_off[STDADK_MAX_LEVELS + 1];  // first block of every level
+  int nbx[STDADK_MAX_LEVELS], nby[STDADK_MAX_LEVELS];
+};
+
+// dW0T[p + k, :] = sum_b phi[b,k] dZ[b,:] for every spatial knot k (each knot block owned by one
+// workgroup: no atomics, summation in sorted-observation order => bitwise reproducible).
+int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st);
+
+// out[perm[i]*Q + q] = in[i*Q + q]
+int unpermute_rows(const float *in, const int *perm, int B, int Q, float *out, hipStream_t st);
+
+}  // namespace stdadk

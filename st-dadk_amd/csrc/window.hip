@@ -1,0 +1,573 @@
+// Index-window path of the first layer (compact-support bases on uniform knot grids).
+//
+// A Wendland / triangular knot with bandwidth 2.5 spacings is non-zero for at most ~21 knots per
+// level around an observation (st_interp.py:152-185 grid, :470-471 support r < 1), so
+// z0 = [X | phi | psi] W0 touches ~63 + Kt rows of W0^T instead of D.  Observations are binned
+// into a G x G cell grid (counting sort, row-major cells) so that
+//   forward : one wave per observation gathers its W0^T rows (1 KiB coalesced each), neighbours in
+//             the sorted order re-use rows from L2; LayerNorm/ReLU/Dropout fused behind it;
+//   backward: every 4x8 knot block is OWNED by one workgroup that walks the observations of the
+//             cells overlapping the block's support box and accumulates phi^T dZ on the matrix
+//             cores — no atomics, fixed summation order.
+// Integer bookkeeping (cell keys, sorted permutation, window origins) follows the bit-exact contract
+// written in include/stdadk.h (pinned by tests); phi uses the same arithmetic as rbf_build.hip.
+#include "window.h"
+
+#include "basis.h"
+
+namespace stdadk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// observation binning
+// ---------------------------------------------------------------------------------------------
+int pick_cell_grid(int64_t B) {
+  int G = 8;
+  while (G < 256 && (int64_t)G * G < B) G <<= 1;   // ~1 observation per cell
+  return G;
+}
+
+__device__ __forceinline__ int cell_of(float x, float y, int G) {
+  int cx = floor_clamp(x * (float)G, G);
+  int cy = floor_clamp(y * (float)G, G);
+  return cx * G + cy;
+}
+
+__global__ void cell_hist_kernel(const float *__restrict__ coords, int B, int G, int *__restrict__ keys,
+                                 int *__restrict__ hist) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int c = cell_of(coords[2 * b], coords[2 * b + 1], G);
+  keys[b] = c;
+  atomicAdd(&hist[c], 1);
+}
+
+// exclusive scan of n <= 65536 counters by one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void cell_scan_kernel(const int *__restrict__ hist, int n,
+                                                         int *__restrict__ cell_start,
+                                                         int *__restrict__ cursor) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int i0 = tid * per, i1 = min(i0 + per, n);
+  int s = 0;
+  for (int i = i0; i < i1; ++i) s += hist[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - s;   // exclusive prefix of this thread's chunk
+  for (int i = i0; i < i1; ++i) {
+    cell_start[i] = run;
+    cursor[i] = run;
+    run += hist[i];
+  }
+  if (tid == 1023) cell_start[n] = part[1023];
+}
+
+__global__ void cell_scatter_kernel(const int *__restrict__ keys, int B, int *__restrict__ cursor,
+                                    int *__restrict__ perm_tmp) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int pos = atomicAdd(&cursor[keys[b]], 1);
+  perm_tmp[pos] = b;
+}
+
+// One thread per cell: order the cell's observations by original index (rank by counting, which
+// makes the permutation independent of the atomics' arrival order) and emit the sorted arrays.
+__global__ void cell_order_kernel(const int *__restrict__ cell_start, int ncell,
+                                  const int *__restrict__ perm_tmp, int *__restrict__ perm,
+                                  const float *__restrict__ coords, const float *__restrict__ t,
+                                  const float *__restrict__ y, int Q, const float *__restrict__ X, int p,
+                                  float *__restrict__ xs, float *__restrict__ ys, float *__restrict__ ts,
+                                  float *__restrict__ y_s, float *__restrict__ X_s) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int s0 = cell_start[c], s1 = cell_start[c + 1];
+  for (int i = s0; i < s1; ++i) {
+    const int b = perm_tmp[i];
+    int rank = 0;
+    for (int j = s0; j < s1; ++j) rank += perm_tmp[j] < b;
+    const int pos = s0 + rank;
+    perm[pos] = b;
+    xs[pos] = coords[2 * b];
+    ys[pos] = coords[2 * b + 1];
+    if (t) ts[pos] = t[b];
+    if (y_s)
+      for (int q = 0; q < Q; ++q) y_s[(int64_t)pos * Q + q] = y[(int64_t)b * Q + q];
+    if (X_s)
+      for (int q = 0; q < p; ++q) X_s[(int64_t)pos * p + q] = X[(int64_t)b * p + q];
+  }
+}
+
+int bin_obs(const float *coords, const float *t, const float *y, int Q, const float *X, int p, int B,
+            int G, const BinBuffers &bb, hipStream_t st) {
+  const int ncell = G * G;
+  hipError_t e = hipMemsetAsync(bb.hist, 0, sizeof(int) * ncell, st);
+  if (e != hipSuccess) { set_error("bin_obs: memset: %s", hipGetErrorString(e)); return (int)e; }
+  const unsigned nb = (unsigned)ceil_div(B, 256);
+  hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, coords, B, G, bb.keys, bb.hist);
+  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, bb.hist, ncell, bb.cell_start, bb.cursor);
+  hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(256), 0, st, bb.keys, B, bb.cursor, bb.perm_tmp);
+  hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)ceil_div(ncell, 128)), dim3(128), 0, st, bb.cell_start,
+                     ncell, bb.perm_tmp, bb.perm, coords, t, y, Q, X, p, bb.xs, bb.ys, bb.ts,
+                     y ? bb.y_s : (float *)nullptr, (X && p > 0) ? bb.X_s : (float *)nullptr);
+  STDADK_CHECK_LAUNCH("bin_obs");
+  return 0;
+}
+
+__global__ void unpermute_kernel(const float *__restrict__ in, const int *__restrict__ perm, int B, int Q,
+                                 float *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Q) return;
+  int r = i / Q, q = i - r * Q;
+  out[(int64_t)perm[r] * Q + q] = in[i];
+}
+
+int unpermute_rows(const float *in, const int *perm, int B, int Q, float *out, hipStream_t st) {
+  hipLaunchKernelGGL(unpermute_kernel, dim3((unsigned)ceil_div((int64_t)B * Q, 256)), dim3(256), 0, st, in,
+                     perm, B, Q, out);
+  STDADK_CHECK_LAUNCH("unpermute");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward:  z0 -> LayerNorm -> ReLU -> Dropout, one wave per observation
+// ---------------------------------------------------------------------------------------------
+constexpr int FW_T = 1024;   // 16 waves share one LDS copy of the temporal rows (1 workgroup per CU)
+constexpr int LIST = 144;   // >= 3*36 + WIN_MAX_P rounded up to 8 (8 levels are chunked below)
+
+template <int CPL>
+struct VecT;
+template <>
+struct VecT<4> { using T = float4; };
+template <>
+struct VecT<2> { using T = float2; };
+template <>
+struct VecT<1> { using T = float; };
+
+template <int CPL>
+__device__ __forceinline__ void fma_row(float *acc, float s, const float *row) {
+  typename VecT<CPL>::T v = *reinterpret_cast<const typename VecT<CPL>::T *>(row);
+  const float *f = reinterpret_cast<const float *>(&v);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = fmaf(s, f[c], acc[c]);
+}
+
+template <int CPL, bool LN, int BASIS>
+__global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int H = 64 * CPL;
+  constexpr int NW = FW_T / 64;
+  const int Kt = a.g.Kt;
+  float *Wt = smem;                                   // [Kt][H] temporal rows of W0^T
+  float *lphi = Wt + (size_t)Kt * H;                  // [NW][LIST]
+  int *lk = reinterpret_cast<int *>(lphi + NW * LIST); // [NW][LIST]
+  float *lpsi = reinterpret_cast<float *>(lk + NW * LIST);  // [NW][Kt_pad]
+  const int Kt_pad = (Kt + 3) & ~3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D0 = a.g.p + a.g.Ks;                      // first temporal row of W0^T
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(a.W0T + (size_t)D0 * H);
+    float4 *dst = reinterpret_cast<float4 *>(Wt);
+    for (int i = tid; i < Kt * H / 4; i += FW_T) dst[i] = src[i];
+  }
+  __syncthreads();
+  float *my_phi = lphi + wave * LIST;
+  int *my_k = lk + wave * LIST;
+  float *my_psi = lpsi + wave * Kt_pad;
+
+  // XCD-aware chunking: workgroups w and w+8 share an XCD (round-robin dispatch), so XCD x walks
+  // the x-th contiguous eighth of the sorted observations and its L2 holds that eighth's W0^T rows.
+  const int w = blockIdx.x, per_x = a.n_wg >> 3;
+  const int chunk = (w & 7) * per_x + (w >> 3);
+  const int r0 = chunk * a.rows_per_wg;
+  const int r1 = min(r0 + a.rows_per_wg, a.B);
+
+  float bias[CPL], gam[CPL], bet[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    bias[c] = a.b0[CPL * lane + c];
+    gam[c] = LN ? a.gamma[CPL * lane + c] : 1.f;
+    bet[c] = LN ? a.beta[CPL * lane + c] : 0.f;
+  }
+  const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint64_t below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+
+  for (int row = r0 + wave; row < r1; row += FW_T / 64) {
+    const float x = a.xs[row], y = a.ys[row], t = a.ts[row];
+    float acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = bias[c];
+
+    // ---- spatial levels, three at a time through the per-wave candidate list
+    for (int l0 = 0; l0 < a.g.n_levels; l0 += 3) {
+      int n = 0;
+      const int l1 = min(l0 + 3, a.g.n_levels);
+      for (int l = l0; l < l1; ++l) {
+        const int side = a.g.side[l];
+        const int win = side < WIN ? side : WIN;
+        const int ix0 = window_start(x, side, win), iy0 = window_start(y, side, win);
+        const int dx = lane / WIN, dy = lane - dx * WIN;
+        float phi = 0.f;
+        int k = 0;
+        if (lane < WIN * WIN && dx < win && dy < win) {
+          k = a.g.off[l] + (ix0 + dx) * side + iy0 + dy;
+          phi = phi_eval<BASIS>(x, y, a.g.centers[2 * k], a.g.centers[2 * k + 1],
+                                knot_scale(a.g.bw[k], a.g.cal));
+        }
+        const uint64_t mask = __ballot(phi != 0.f);
+        if (phi != 0.f) {
+          const int pos = n + __popcll(mask & below);
+          my_phi[pos] = phi;
+          my_k[pos] = a.g.p + k;
+        }
+        n += __popcll(mask);
+      }
+      if (l0 == 0 && a.g.p > 0) {            // covariate columns [0, p): dense
+        if (lane < a.g.p) {
+          my_phi[n + lane] = a.Xs[(size_t)row * a.g.p + lane];
+          my_k[n + lane] = lane;
+        }
+        n += a.g.p;
+      }
+      const int npad = (n + 7) & ~7;
+      if (lane < npad - n) { my_phi[n + lane] = 0.f; my_k[n + lane] = 0; }
+      __builtin_amdgcn_wave_barrier();
+      for (int e0 = 0; e0 < npad; e0 += 8) {
+        float pv[8];
+        const float *rp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pv[e] = my_phi[e0 + e];
+          rp[e] = a.W0T + (size_t)my_k[e0 + e] * H + CPL * lane;
+        }
+        typename VecT<CPL>::T wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(rp[e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float *f = reinterpret_cast<const float *>(&wv[e]);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[c] = fmaf(pv[e], f[c], acc[c]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- temporal basis: rows from LDS
+    for (int j = lane; j < Kt; j += 64) {
+      float v = psi_eval(t, a.g.t_centers[j], a.g.t_bw[j]);
+      my_psi[j] = v;
+      a.psi[(size_t)row * a.ld_psi + j] = v;
+    }
+    for (int j = Kt + lane; j < a.ld_psi; j += 64) a.psi[(size_t)row * a.ld_psi + j] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < Kt; ++j) fma_row<CPL>(acc, my_psi[j], Wt + (size_t)j * H + CPL * lane);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- LayerNorm -> ReLU -> Dropout (row-local: this wave owns the whole row)
+    float mean = 0.f, rs = 1.f;
+    if (LN) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) s += acc[c];
+      mean = wave_sum(s) / (float)H;
+      float sq = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { float d = acc[c] - mean; sq += d * d; }
+      rs = 1.0f / sqrtf(wave_sum(sq) / (float)H + a.eps);
+      if (lane == 0) a.rstd[row] = rs;
+    }
+    float xh[CPL], av[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      xh[c] = LN ? (acc[c] - mean) * rs : acc[c];
+      float u = LN ? fmaf(xh[c], gam[c], bet[c]) : xh[c];
+      float v = fmaxf(u, 0.f);
+      if (a.drop_p > 0.f) {
+        bool keep = drop_keep(seed, 0, (int64_t)row * H + CPL * lane + c, a.drop_p);
+        v = keep ? v * keep_scale : 0.f;
+      }
+      av[c] = v;
+    }
+    typename VecT<CPL>::T o1, o2;
+    float *f1 = reinterpret_cast<float *>(&o1), *f2 = reinterpret_cast<float *>(&o2);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { f1[c] = xh[c]; f2[c] = av[c]; }
+    *reinterpret_cast<typename VecT<CPL>::T *>(a.xhat + (size_t)row * H + CPL * lane) = o1;
+    *reinterpret_cast<typename VecT<CPL>::T *>(a.act + (size_t)row * H + CPL * lane) = o2;
+  }
+}
+
+bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt) {
+  if (n_levels <= 0 || n_levels > STDADK_MAX_LEVELS) return false;
+  if (basis != STDADK_BASIS_WENDLAND && basis != STDADK_BASIS_TRIANGULAR) return false;  // compact support
+  if (H != 128 && H != 256) return false;
+  if (p > WIN_MAX_P) return false;
+  if ((size_t)Kt * H * 4 > 96 * 1024) return false;   // temporal rows of W0^T live in LDS
+  return true;
+}
+
+template <int CPL, bool LN, int BASIS>
+static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
+  const int Kt_pad = (a.g.Kt + 3) & ~3;
+  size_t lds = ((size_t)a.g.Kt * 64 * CPL + (FW_T / 64) * (LIST * 2 + Kt_pad)) * sizeof(float);
+  auto kern = l1_window_fwd_kernel<CPL, LN, BASIS>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("l1_window_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.n_wg), dim3(FW_T), lds, st, a);
+  STDADK_CHECK_LAUNCH("l1_window_forward");
+  return 0;
+}
+
+int l1_window_forward(const L1FwdArgs &a_in, int basis, bool ln, hipStream_t st) {
+  L1FwdArgs a = a_in;
+  // one 16-wave workgroup per CU (~95 KiB LDS), multiple of 8 for the XCD mapping
+  int n_wg = 256;
+  while (n_wg > 8 && (int64_t)(n_wg / 2) * (FW_T / 64) >= a.B) n_wg >>= 1;
+  a.n_wg = n_wg;
+  a.rows_per_wg = (int)ceil_div(a.B, n_wg);
+#define GO(CPL_) \
+  (basis == STDADK_BASIS_WENDLAND ? (ln ? launch_fwd<CPL_, true, 0>(a, st) : launch_fwd<CPL_, false, 0>(a, st)) \
+                                  : (ln ? launch_fwd<CPL_, true, 2>(a, st) : launch_fwd<CPL_, false, 2>(a, st)))
+  if (a.H == 256) return GO(4);
+  if (a.H == 128) return GO(2);
+#undef GO
+  set_error("l1_window_forward: H=%d unsupported", a.H);
+  return STDADK_E_SHAPE;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: dW0T[p+k, :] = sum_b phi[b,k] dZ[b,:], 4x8 knot block per workgroup
+// ---------------------------------------------------------------------------------------------
+constexpr int KBX = 4, KBY = 8, KB = KBX * KBY;   // 32 knots = one MFMA row tile
+constexpr int OT = 32;                            // observations per MFMA k-tile
+constexpr int MAX_SEG = 256;                      // cell rows a block may overlap (G <= 256)
+
+template <int TN, int BASIS>
+__global__ __launch_bounds__(256) void l1_window_bwd_kernel(L1BwdArgs a) {
+  constexpr int H = 128 * TN;
+  __shared__ __attribute__((aligned(16))) float As[OT * KB];      // [obs][knot]
+  __shared__ __attribute__((aligned(16))) float Bs[OT * H];       // [obs][col]
+  __shared__ int seg_start[MAX_SEG], seg_pref[MAX_SEG + 1];
+  __shared__ int s_idx[OT];
+  __shared__ float s_x[OT], s_y[OT];
+  __shared__ int s_kidx[KB];
+  __shared__ float s_box[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // which level / block
+  int l = 0;
+  while (l + 1 < a.g.n_levels && (int)blockIdx.x >= a.blk_off[l + 1]) ++l;
+  const int bid = blockIdx.x - a.blk_off[l];
+  const int side = a.g.side[l];
+  const int bx = bid / a.nby[l], by = bid - bx * a.nby[l];
+
+  // this thread's knot (for the phi tile): i = tid & 31
+  const int ki = tid & (KB - 1);
+  const int kix = bx * KBX + ki / KBY, kiy = by * KBY + (ki % KBY);
+  const bool kvalid = kix < side && kiy < side;
+  const int kk = kvalid ? a.g.off[l] + kix * side + kiy : a.g.off[l];
+  const float kcx = a.g.centers[2 * kk], kcy = a.g.centers[2 * kk + 1];
+  const float ksc = knot_scale(a.g.bw[kk], a.g.cal);
+  if (tid < KB) s_kidx[tid] = kvalid ? kk : -1;
+  if (tid == 0) {
+    // support box of the block from the knot table itself (first / last valid knot per axis)
+    const int ix_lo = bx * KBX, ix_hi = min(bx * KBX + KBX - 1, side - 1);
+    const int iy_lo = by * KBY, iy_hi = min(by * KBY + KBY - 1, side - 1);
+    const int k00 = a.g.off[l] + ix_lo * side + iy_lo, k11 = a.g.off[l] + ix_hi * side + iy_hi;
+    const float r = a.g.bw[k00] * a.g.cal;     // support radius: r = dist/(bw*cal) < 1
+    s_box[0] = a.g.centers[2 * k00] - r;     s_box[1] = a.g.centers[2 * k11] + r;
+    s_box[2] = a.g.centers[2 * k00 + 1] - r; s_box[3] = a.g.centers[2 * k11 + 1] + r;
+  }
+  __syncthreads();
+  // cells overlapping the box, one cell of margin against rounding
+  const int G = a.G;
+  const int cx_lo = max(floor_clamp(s_box[0] * (float)G, G) - 1, 0);
+  const int cx_hi = min(floor_clamp(s_box[1] * (float)G, G) + 1, G - 1);
+  const int cy_lo = max(floor_clamp(s_box[2] * (float)G, G) - 1, 0);
+  const int cy_hi = min(floor_clamp(s_box[3] * (float)G, G) + 1, G - 1);
+  const int nseg = cx_hi - cx_lo + 1;
+  if (tid < nseg) {
+    const int cx = cx_lo + tid;
+    seg_start[tid] = a.cell_start[cx * G + cy_lo];
+    seg_pref[tid + 1] = a.cell_start[cx * G + cy_hi + 1] - seg_start[tid];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    seg_pref[0] = 0;
+    for (int i = 0; i < nseg; ++i) seg_pref[i + 1] += seg_pref[i];
+  }
+  __syncthreads();
+  const int total = seg_pref[nseg];
+  const int ntile = (total + OT - 1) / OT;
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int wn = wave * (H / 4);     // this wave's first output column
+
+  for (int tile = 0; tile < ntile; ++tile) {
+    if (tid < OT) {
+      const int pos = tile * OT + tid;
+      int idx = -1;
+      if (pos < total) {
+        int s = 0;
+        while (pos >= seg_pref[s + 1]) ++s;
+        idx = seg_start[s] + (pos - seg_pref[s]);
+      }
+      s_idx[tid] = idx;
+      s_x[tid] = idx >= 0 ? a.xs[idx] : 0.f;
+      s_y[tid] = idx >= 0 ? a.ys[idx] : 0.f;
+    }
+    __syncthreads();
+    // phi tile: As[obs][knot]
+#pragma unroll
+    for (int j = 0; j < OT * KB / 256; ++j) {
+      const int s = (tid >> 5) + 8 * j;
+      float v = 0.f;
+      if (kvalid && s_idx[s] >= 0) v = phi_eval<BASIS>(s_x[s], s_y[s], kcx, kcy, ksc);
+      As[s * KB + ki] = v;
+    }
+    // dZ tile: Bs[obs][col], 8 threads per row
+    {
+      const int s = tid >> 3, part = tid & 7;
+      const int idx = s_idx[s];
+      const float4 *src = reinterpret_cast<const float4 *>(a.dZ + (size_t)(idx >= 0 ? idx : 0) * H);
+      float4 *dst = reinterpret_cast<float4 *>(Bs + s * H);
+#pragma unroll
+      for (int j = 0; j < H / 32; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx >= 0) v = src[part + 8 * j];
+        dst[part + 8 * j] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < OT / 8; ++s) {
+      float fa[4], fb[TN][4];
+      const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fa[e] = As[(8 * s + 4 * h + e) * KB + c];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fb[j][e] = Bs[(8 * s + 4 * h + e) * H + wn + j * 32 + c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc[j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // every valid knot row of the block is written (zeros when no observation is in reach)
+  const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int k = s_kidx[i];
+      if (k >= 0) a.dW0T[(size_t)(a.g.p + k) * H + wn + j * 32 + c] = acc[j][r];
+    }
+}
+
+int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st) {
+  int nblk = 0;
+  for (int l = 0; l < a.g.n_levels; ++l) {
+    a.blk_off[l] = nblk;
+    a.nbx[l] = (int)ceil_div(a.g.side[l], KBX);
+    a.nby[l] = (int)ceil_div(a.g.side[l], KBY);
+    nblk += a.nbx[l] * a.nby[l];
+  }
+  a.blk_off[a.g.n_levels] = nblk;
+  STDADK_REQUIRE(a.G <= MAX_SEG, STDADK_E_ARG, "l1_window_backward: G too large");
+#define GO(TN_, BS_) hipLaunchKernelGGL((l1_window_bwd_kernel<TN_, BS_>), dim3((unsigned)nblk), dim3(256), 0, st, a)
+  if (a.H == 256) { if (basis == STDADK_BASIS_WENDLAND) GO(2, 0); else GO(2, 2); }
+  else if (a.H == 128) { if (basis == STDADK_BASIS_WENDLAND) GO(1, 0); else GO(1, 2); }
+  else { set_error("l1_window_backward: H=%d unsupported", a.H); return STDADK_E_SHAPE; }
+#undef GO
+  STDADK_CHECK_LAUNCH("l1_window_backward");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// diagnostic: window origins (bit-exact contract of include/stdadk.h)
+// ---------------------------------------------------------------------------------------------
+struct LevelTable { int side[STDADK_MAX_LEVELS]; int off[STDADK_MAX_LEVELS]; };
+
+__global__ void knot_windows_kernel(const float *__restrict__ coords, int B, int L, LevelTable lt, int p,
+                                    int *__restrict__ ix0, int *__restrict__ iy0, int *__restrict__ col0) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * L) return;
+  int b = i / L, l = i - b * L;
+  int side = lt.side[l], off = lt.off[l];
+  int win = side < WIN ? side : WIN;
+  int x0 = window_start(coords[2 * b], side, win), y0 = window_start(coords[2 * b + 1], side, win);
+  ix0[i] = x0;
+  iy0[i] = y0;
+  col0[i] = p + off + x0 * side + y0;
+}
+
+}  // namespace stdadk
+
+using namespace stdadk;
+
+extern "C" int stdadk_knot_windows_i32(const float *coords, int64_t B, const int32_t *sides_host,
+                                       int32_t n_levels, int32_t p, int32_t *ix0, int32_t *iy0,
+                                       int32_t *col0, stdadk_stream_t stream) {
+  STDADK_REQUIRE(B >= 0 && n_levels > 0 && n_levels <= STDADK_MAX_LEVELS, STDADK_E_ARG, "knot_windows: bad sizes");
+  if (B == 0) return 0;
+  STDADK_REQUIRE(coords && sides_host && ix0 && iy0 && col0, STDADK_E_ARG, "knot_windows: NULL pointer");
+  LevelTable lt;
+  int off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    STDADK_REQUIRE(sides_host[l] >= 1, STDADK_E_ARG, "knot_windows: side < 1");
+    lt.side[l] = sides_host[l];
+    lt.off[l] = off;
+    off += sides_host[l] * sides_host[l];
+  }
+  hipLaunchKernelGGL(knot_windows_kernel, dim3((unsigned)ceil_div(B * n_levels, 256)), dim3(256), 0,
+                     (hipStream_t)stream, coords, (int)B, (int)n_levels, lt, p, ix0, iy0, col0);
+  STDADK_CHECK_LAUNCH("knot_windows");
+  return 0;
+}
+
+extern "C" size_t stdadk_bin_workspace_bytes(int64_t B, int32_t G) {
+  if (B < 0 || G < 1 || G > 256) return 0;
+  return (size_t)(2 * align_up((size_t)G * G + 1, 64) + 2 * align_up((size_t)B, 64)) * sizeof(int) +
+         3 * align_up((size_t)B, 64) * sizeof(float);
+}
+
+extern "C" int stdadk_bin_obs_f32(const float *coords, int64_t B, int32_t G, int32_t *keys,
+                                  int32_t *cell_start, int32_t *perm, void *workspace,
+                                  size_t workspace_bytes, stdadk_stream_t stream) {
+  STDADK_REQUIRE(B >= 0 && B < (1ll << 31), STDADK_E_ARG, "bin_obs: bad B");
+  STDADK_REQUIRE(G >= 1 && G <= 256, STDADK_E_ARG, "bin_obs: G must be in [1,256]");
+  if (B == 0) return 0;
+  STDADK_REQUIRE(coords && keys && cell_start && perm && workspace, STDADK_E_ARG, "bin_obs: NULL pointer");
+  STDADK_REQUIRE(workspace_bytes >= stdadk_bin_workspace_bytes(B, G), STDADK_E_WORKSPACE, "bin_obs: workspace too small");
+  int *w = (int *)workspace;
+  BinBuffers bb;
+  size_t nc = align_up((size_t)G * G + 1, 64), nb = align_up((size_t)B, 64);
+  bb.keys = keys; bb.cell_start = cell_start; bb.perm = perm;
+  bb.hist = w; w += nc;
+  bb.cursor = w; w += nc;
+  bb.perm_tmp = w; w += nb;
+  w += nb;
+  bb.xs = (float *)w; bb.ys = bb.xs + nb; bb.ts = bb.ys + nb;
+  bb.y_s = nullptr; bb.X_s = nullptr;
+  return bin_obs(coords, nullptr, nullptr, 0, nullptr, 0, (int)B, G, bb, (hipStream_t)stream);
+}

@@ -31,6 +31,16 @@ class MlpTensors(C.Structure):
                 ("ln_g", C.c_void_p * MAX_HIDDEN), ("ln_b", C.c_void_p * MAX_HIDDEN)]
 
 
+class BasisDesc(C.Structure):
+    _fields_ = [("p", C.c_int32), ("basis", C.c_int32), ("n_levels", C.c_int32),
+                ("side", C.c_int32 * 8), ("Ks", C.c_int64), ("Kt", C.c_int64),
+                ("s_centers", C.c_void_p), ("s_bw", C.c_void_p), ("t_centers", C.c_void_p),
+                ("t_bw", C.c_void_p)]
+
+
+FLAG_DENSE = 1
+FLAG_W0_T = 2
+
 _lib = None
 
 _SIGNATURES = {
@@ -50,6 +60,26 @@ _SIGNATURES = {
                                           C.POINTER(C.c_void_p), C.c_void_p]),
     "stdadk_mse_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
+    "stdadk_step_uses_window": (C.c_int32, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.c_int32]),
+    "stdadk_step_workspace_bytes": (C.c_size_t, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.c_int64,
+                                                 C.c_int32]),
+    "stdadk_forward_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_int32, C.c_uint64, C.c_void_p,
+                                     C.c_int32, C.c_void_p]),
+    "stdadk_backward_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
+                                      C.POINTER(MlpTensors), C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_uint64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "stdadk_train_fwd_bwd_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc),
+                                           C.POINTER(MlpTensors), C.POINTER(MlpTensors), C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
+                                           C.c_void_p, C.c_int32, C.c_void_p]),
+    "stdadk_bin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "stdadk_bin_obs_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "stdadk_knot_windows_i32": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int32,
+                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "stdadk_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "stdadk_gemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
@@ -75,7 +105,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError => the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.stdadk_abi_version() != 1:
+        if handle.stdadk_abi_version() != 2:
             raise NativeLibraryError("libstdadk.so ABI version mismatch")
         _lib = handle
     return _lib
@@ -205,6 +235,85 @@ def gemm(A, a_km, Bm, b_km, M, N, K, bias=None, out=None, workspace=None):
                                workspace.data_ptr() if workspace is not None else None,
                                workspace.numel() * 4 if workspace is not None else 0, _stream())
     _check(rc, "stdadk_gemm_f32")
+    return out
+
+
+def make_basis(p, basis, sides, s_centers, s_bw, t_centers, t_bw):
+    """ABI descriptor of the knot tables; `sides` = level side lengths of a uniform grid or None."""
+    b = BasisDesc()
+    b.p, b.basis = int(p), BASIS_KIND[basis]
+    b.n_levels = len(sides) if sides else 0
+    if b.n_levels > 8:
+        b.n_levels = 0          # more levels than the window path tracks: dense path only
+    for i in range(b.n_levels):
+        b.side[i] = int(sides[i])
+    b.Ks, b.Kt = s_centers.shape[0], t_centers.shape[0]
+    b.s_centers, b.s_bw = _dev(s_centers, "s_centers"), _dev(s_bw, "s_bw")
+    b.t_centers, b.t_bw = _dev(t_centers, "t_centers"), _dev(t_bw, "t_bw")
+    return b
+
+
+def step_uses_window(basis, desc, flags):
+    return bool(lib().stdadk_step_uses_window(C.byref(basis), C.byref(desc), flags))
+
+
+def step_workspace_bytes(basis, desc, B, flags):
+    n = lib().stdadk_step_workspace_bytes(C.byref(basis), C.byref(desc), B, flags)
+    if n == 0:
+        raise RuntimeError("stdadk_step_workspace_bytes: invalid descriptors")
+    return n
+
+
+def forward(basis, desc, params, coords, t, X, B, y_pred, workspace, flags, training=False, seed=0,
+            step_dev=None):
+    rc = lib().stdadk_forward_f32(C.byref(basis), C.byref(desc), C.byref(params), _dev(coords, "coords"),
+                                  _dev(t, "t"), _dev(X, "X"), B, _dev(y_pred, "y_pred"),
+                                  workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                  int(training), seed, _dev(step_dev, "step_dev"), flags, _stream())
+    _check(rc, "stdadk_forward_f32")
+
+
+def backward(basis, desc, params, grads, B, dY, workspace, flags, seed=0, step_dev=None):
+    rc = lib().stdadk_backward_f32(C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads), B,
+                                   _dev(dY, "dY"), workspace.data_ptr(),
+                                   workspace.numel() * workspace.element_size(), seed,
+                                   _dev(step_dev, "step_dev"), flags, _stream())
+    _check(rc, "stdadk_backward_f32")
+
+
+def train_fwd_bwd(basis, desc, params, grads, coords, t, X, y, B, grad_scale, loss_sum, y_pred,
+                  workspace, flags, seed=0, step_dev=None):
+    rc = lib().stdadk_train_fwd_bwd_f32(C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads),
+                                        _dev(coords, "coords"), _dev(t, "t"), _dev(X, "X"), _dev(y, "y"),
+                                        B, grad_scale, _dev(loss_sum, "loss_sum"), _dev(y_pred, "y_pred"),
+                                        workspace.data_ptr(),
+                                        workspace.numel() * workspace.element_size(), seed,
+                                        _dev(step_dev, "step_dev"), flags, _stream())
+    _check(rc, "stdadk_train_fwd_bwd_f32")
+
+
+def bin_obs(coords, G):
+    """(keys[B], cell_start[G*G+1], perm[B]) int32 device tensors of the window path's binning."""
+    B = coords.shape[0]
+    dev = coords.device
+    keys = torch.empty(B, dtype=torch.int32, device=dev)
+    cell_start = torch.empty(G * G + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(B, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(lib().stdadk_bin_workspace_bytes(B, G) // 4, 1), dtype=torch.float32, device=dev)
+    rc = lib().stdadk_bin_obs_f32(_dev(coords, "coords"), B, G, keys.data_ptr(), cell_start.data_ptr(),
+                                  perm.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
+    _check(rc, "stdadk_bin_obs_f32")
+    return keys, cell_start, perm
+
+
+def knot_windows(coords, sides, p):
+    B, L = coords.shape[0], len(sides)
+    dev = coords.device
+    out = [torch.empty(B, L, dtype=torch.int32, device=dev) for _ in range(3)]
+    arr = (C.c_int32 * L)(*sides)
+    rc = lib().stdadk_knot_windows_i32(_dev(coords, "coords"), B, arr, L, p, out[0].data_ptr(),
+                                       out[1].data_ptr(), out[2].data_ptr(), _stream())
+    _check(rc, "stdadk_knot_windows_i32")
     return out
 
 

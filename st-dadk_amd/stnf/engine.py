@@ -20,10 +20,13 @@ import torch.distributed as dist
 from . import _native as N
 
 
-def flatten_parameters(model):
-    """Move every trainable parameter of `model` into one flat fp32 buffer (views keep the
-    original shapes/names).  Each parameter is padded to a multiple of 4 floats so every view
-    is 16-byte aligned.  Returns (flat, [(name, offset, numel)])."""
+def flatten_parameters(model, transpose_first=True):
+    """Move every trainable parameter of `model` into one flat fp32 buffer (the parameters become
+    views, so state_dict()/checkpoints keep their names and shapes).  Each parameter is padded to a
+    multiple of 4 floats so every view is 16-byte aligned.  With `transpose_first` the first
+    Linear's weight is STORED (in,out) row-major — the layout the window kernels gather rows from —
+    and `model.mlp[0].weight` becomes its .t() view (same values, shape (out,in)).
+    Returns (flat, [(name, offset, numel)])."""
     params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     dev = params[0][1].device
     offs, total = [], 0
@@ -31,9 +34,15 @@ def flatten_parameters(model):
         offs.append((n, total, p.numel()))
         total += (p.numel() + 3) // 4 * 4
     flat = torch.zeros(total, device=dev, dtype=torch.float32)
+    first_w = model.mlp[0].weight
     for (n, p), (_, o, k) in zip(params, offs):
-        flat[o:o + k].copy_(p.data.reshape(-1))
-        p.data = flat[o:o + k].view(p.shape)
+        if transpose_first and p is first_w:
+            out_f, in_f = p.shape
+            flat[o:o + k].view(in_f, out_f).copy_(p.data.t())
+            p.data = flat[o:o + k].view(in_f, out_f).t()
+        else:
+            flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + k].view(p.shape)
     return flat, offs
 
 
@@ -42,12 +51,12 @@ class TrainStep:
 
     def __init__(self, model, lr=2e-2, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
                  grad_clip=10.0, ema_decay=None, max_batch=4096, use_graph=False,
-                 process_group=None, distributed=None):
+                 process_group=None, distributed=None, force_dense=False):
         self.model = model
         self.dev = next(model.parameters()).device
         if self.dev.type != "cuda":
             raise RuntimeError("TrainStep needs the model on a HIP device; there is no CPU path")
-        self.flat, self.offsets = flatten_parameters(model)
+        self.flat, self.offsets = flatten_parameters(model, transpose_first=True)
         self.grad = torch.zeros_like(self.flat)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
@@ -57,27 +66,31 @@ class TrainStep:
         self.grad_clip = float(grad_clip or 0.0)
         self.step_count = 0
         self.max_batch = int(max_batch)
-        self.desc = model._native_desc()
-        self.params_t = model._native_tensors()
-        # gradient views in _param_list() order
+        self.state = model._step_state(self.dev, force_dense=force_dense, training=True)
+        assert self.state.w0_transposed
+        self.uses_window = N.step_uses_window(self.state.basis, self.state.desc, self.state.flags)
+        # gradient views in _param_list() order; dW0 is stored transposed like W0
         views = []
         by_name = {n: (o, k) for n, o, k in self.offsets}
+        first_w = model.mlp[0].weight
         for n, p in model.named_parameters():
             if p.requires_grad:
                 o, k = by_name[n]
-                views.append(self.grad[o:o + k].view(p.shape))
+                if p is first_w:
+                    views.append(self.grad[o:o + k].view(p.shape[1], p.shape[0]))
+                else:
+                    views.append(self.grad[o:o + k].view(p.shape))
         self.grad_views = views
         self.grads_t = model._pack(views)
         B = self.max_batch
-        ld = (model.input_dim + 31) // 32 * 32
-        self.feats = torch.zeros(B, ld, device=self.dev)
-        self.ws = torch.empty(N.mlp_workspace_bytes(self.desc, B) // 4, device=self.dev)
+        self.ws = torch.empty(N.step_workspace_bytes(self.state.basis, self.state.desc, B, self.state.flags) // 4,
+                              device=self.dev)
         self.y_pred = torch.empty(B, model.output_dim, device=self.dev)
-        self.dY = torch.empty(B, model.output_dim, device=self.dev)
         self.loss_sum = torch.zeros(1, device=self.dev)       # running sum of squared errors
         self.sumsq = torch.zeros(1, device=self.dev)
         self.lr_dev = torch.full((1,), self.lr, device=self.dev)
         self.step_dev = torch.zeros(1, device=self.dev, dtype=torch.int32)
+        self.seed = 0x5DEECE66D
         self.rows_seen = 0
         # distributed
         if distributed is None:
@@ -98,16 +111,12 @@ class TrainStep:
 
     def _enqueue(self, X, coords, t, y, B, global_rows):
         """All kernels of one step on the current stream (capturable: no sync, no allocation)."""
-        m = self.model
-        feats = self.feats[:B]
-        N.rbf_build(coords, t, X if (m.p > 0 and X is not None and X.numel() > 0) else None,
-                    m.spatial_basis.centers, m.spatial_basis._bandwidths, m.spatial_basis_function,
-                    m.temporal_basis.centers, m.temporal_basis.bandwidths, feats)
-        seed = (0x5DEECE66D * (self.step_count + 1)) & (2 ** 62 - 1)
-        N.mlp_forward(self.desc, self.params_t, feats, B, self.y_pred[:B], self.ws, True, seed)
-        # d(mean over the GLOBAL batch)/dy: each rank scales by 1/global_rows, the all-reduce SUMs
-        N.mse(self.y_pred[:B], y, 1.0 / (global_rows * m.output_dim), self.dY[:B], self.loss_sum)
-        N.mlp_backward(self.desc, self.params_t, self.grads_t, feats, B, self.dY[:B], self.ws, seed)
+        st = self.state
+        Q = self.model.output_dim
+        # d(mean over the GLOBAL batch)/dparams: each rank scales by 1/global_rows, the all-reduce SUMs
+        N.train_fwd_bwd(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, B,
+                        1.0 / (global_rows * Q), self.loss_sum, self.y_pred, self.ws, st.flags,
+                        seed=self.seed, step_dev=self.step_dev)
         if self.distributed:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
         if self.grad_clip > 0:
@@ -128,6 +137,10 @@ class TrainStep:
         coords = coords.contiguous().float()
         t = t.contiguous().float().view(-1)
         y = y.contiguous().float()
+        if self.model.p > 0:
+            X = X.contiguous().float()
+        else:
+            X = None
         if self.use_graph and not self.distributed:
             self._step_graph(X, coords, t, y, B, global_rows)
         else:
@@ -138,18 +151,18 @@ class TrainStep:
     def _step_graph(self, X, coords, t, y, B, global_rows):
         if self._graph is None or self._g_B != (B, global_rows):
             p = self.model.p
-            self._g_in = (torch.empty(B, max(p, 1), device=self.dev) if p > 0 else None,
+            self._g_in = (torch.empty(B, p, device=self.dev) if p > 0 else None,
                           torch.empty(B, 2, device=self.dev), torch.empty(B, device=self.dev),
                           torch.empty(B, self.model.output_dim, device=self.dev))
             self._g_B = (B, global_rows)
-            # the captured AdamW reads lr / step from device scalars so a replay advances them
+            # AdamW and the dropout generator read lr / step from device scalars, so a replay
+            # advances them; capture itself executes nothing
             self.step_dev.fill_(self.step_count)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._enqueue(self._g_in[0], self._g_in[1], self._g_in[2], self._g_in[3], B, global_rows)
             self._graph = g
-            # capture does not execute: state is untouched
         gi = self._g_in
         if gi[0] is not None:
             gi[0].copy_(X)
@@ -164,31 +177,36 @@ class TrainStep:
             self.rows_seen = 0
         return val
 
+    def swap_in_ema(self):
+        """Exchange the live parameters with the EMA shadow (validation under EMA weights,
+        scripts/train_st_interp.py:739,790); call again to swap back."""
+        if self.ema is None:
+            raise RuntimeError("EMA is disabled")
+        tmp = self.flat.clone()
+        self.flat.copy_(self.ema)
+        self.ema.copy_(tmp)
+
 
 class Predictor:
     """Dense-grid inference (reference scripts/train_st_interp.py:1091-1107,1232-1248,1378-1409;
-    evaluate_model :884-961): batched feature build + MLP forward into a preallocated output,
-    optionally replayed from a hipGraph per fixed-size chunk."""
+    evaluate_model :884-961): batched forward into a preallocated output, chunked so the workspace
+    stays bounded, each full chunk replayed from a hipGraph."""
 
-    def __init__(self, model, chunk=65536, use_graph=True):
+    def __init__(self, model, chunk=65536, use_graph=True, force_dense=False):
         self.model = model
         self.dev = next(model.parameters()).device
         self.chunk = int(chunk)
-        self.desc = model._native_desc()
-        ld = (model.input_dim + 31) // 32 * 32
-        self.feats = torch.zeros(self.chunk, ld, device=self.dev)
-        self.ws = torch.empty(N.mlp_workspace_bytes(self.desc, self.chunk) // 4, device=self.dev)
+        self.state = model._step_state(self.dev, force_dense=force_dense, training=False)
+        self.ws = torch.empty(N.step_workspace_bytes(self.state.basis, self.state.desc, self.chunk,
+                                                     self.state.flags) // 4, device=self.dev)
         self.use_graph = use_graph
         self._graph = None
         self._in = (torch.empty(self.chunk, 2, device=self.dev), torch.empty(self.chunk, device=self.dev))
         self._out = torch.empty(self.chunk, model.output_dim, device=self.dev)
 
     def _enqueue(self, coords, t, out, B):
-        m = self.model
-        N.rbf_build(coords, t, None, m.spatial_basis.centers, m.spatial_basis._bandwidths,
-                    m.spatial_basis_function, m.temporal_basis.centers, m.temporal_basis.bandwidths,
-                    self.feats[:B])
-        N.mlp_forward(self.desc, m._native_tensors(), self.feats[:B], B, out, self.ws, False, 0)
+        st = self.state
+        N.forward(st.basis, st.desc, st.params, coords, t, None, B, out, self.ws, st.flags, training=False)
 
     @torch.no_grad()
     def predict(self, coords, t):

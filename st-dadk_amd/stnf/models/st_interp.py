@@ -120,33 +120,45 @@ class TemporalBasisEmbedding(nn.Module):
         return out
 
 
-class _MlpFunction(torch.autograd.Function):
-    """features -> y_pred through libstdadk; backward fills the parameter gradients.
-    No gradient flows into the features (fixed knots are buffers; reference :106-107)."""
+class _StepFunction(torch.autograd.Function):
+    """(X, coords, t) -> y_pred through libstdadk's step-level entry points; backward fills the
+    parameter gradients.  No gradient flows into the inputs or the knots (fixed knots are
+    buffers; reference :106-107)."""
 
     @staticmethod
-    def forward(ctx, model, features, training, *params):
-        desc, tensors = model._native_desc(), model._native_tensors()
-        B = features.shape[0]
-        y = torch.empty(B, model.output_dim, device=features.device, dtype=torch.float32)
-        ws = torch.empty(N.mlp_workspace_bytes(desc, B) // 4, device=features.device,
-                         dtype=torch.float32)
+    def forward(ctx, model, X, coords, t, training, *params):
+        st = model._step_state(coords.device, force_dense=model.force_dense_path, training=training)
+        B = coords.shape[0]
+        y = torch.empty(B, model.output_dim, device=coords.device, dtype=torch.float32)
+        ws = torch.empty(N.step_workspace_bytes(st.basis, st.desc, B, st.flags) // 4,
+                         device=coords.device, dtype=torch.float32)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and model.dropout_p > 0) else 0
-        N.mlp_forward(desc, tensors, features, B, y, ws, training, seed)
-        ctx.model, ctx.desc, ctx.seed, ctx.B = model, desc, seed, B
-        ctx.save_for_backward(features, ws)
+        N.forward(st.basis, st.desc, st.params, coords, t, X, B, y, ws, st.flags, training=True, seed=seed)
+        ctx.model, ctx.st, ctx.seed, ctx.B = model, st, seed, B
+        ctx.save_for_backward(ws)
         return y
 
     @staticmethod
     def backward(ctx, dY):
-        features, ws = ctx.saved_tensors
-        model = ctx.model
+        (ws,) = ctx.saved_tensors
+        model, st = ctx.model, ctx.st
         plist = model._param_list()
-        grads = [torch.empty_like(p) for p in plist]
-        gt = model._pack(grads)
-        N.mlp_backward(ctx.desc, model._native_tensors(), gt, features, ctx.B,
-                       dY.contiguous().float(), ws, ctx.seed)
-        return (None, None, None) + tuple(grads)
+        grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in plist]
+        if st.w0_transposed:
+            # dW0 arrives as dW0^T (in,out); hand autograd its transpose view, shape (out,in)
+            g0t = torch.empty(plist[0].shape[1], plist[0].shape[0], device=dY.device, dtype=torch.float32)
+            grads[0] = g0t.t()
+            gt = model._pack([g0t] + grads[1:])
+        else:
+            gt = model._pack(grads)
+        N.backward(st.basis, st.desc, st.params, gt, ctx.B, dY.contiguous().float(), ws, st.flags,
+                   seed=ctx.seed)
+        return (None, None, None, None, None) + tuple(grads)
+
+
+class _StepState:
+    """ABI descriptors for one forward/backward pair (keeps the tensors they point to alive)."""
+    __slots__ = ("basis", "desc", "params", "flags", "w0_transposed", "keep")
 
 
 class STInterpMLP(nn.Module):
@@ -196,6 +208,8 @@ class STInterpMLP(nn.Module):
         self.mlp = nn.Sequential(*layers)
         self.mlp_trunk = None
         self.delta_params = None
+        # diagnostics: True forces the materialising (dense) kernels even where the window path applies
+        self.force_dense_path = False
 
     # ---- native plumbing ---------------------------------------------------------------
     def _linears(self):
@@ -219,12 +233,41 @@ class STInterpMLP(nn.Module):
                 gs.append(next(it)); betas.append(next(it))
         return N.make_tensors(Ws, bs, gs if self.layernorm else None, betas if self.layernorm else None)
 
-    def _native_desc(self):
+    def _native_desc(self, training=True):
         return N.make_desc(self.input_dim, self.hidden_dims, self.output_dim, self.layernorm,
-                           self.dropout_p)
+                           self.dropout_p if training else 0.0)
 
     def _native_tensors(self):
         return self._pack([p.data for p in self._param_list()])
+
+    def _basis_desc(self):
+        sb, tb = self.spatial_basis, self.temporal_basis
+        sides = sb.level_sides if sb.init_method == 'uniform' else None
+        return N.make_basis(self.p, self.spatial_basis_function, sides, sb.centers, sb._bandwidths,
+                            tb.centers, tb.bandwidths)
+
+    def _step_state(self, device, force_dense=False, training=True):
+        """Descriptors of the step-level ABI.  The window path wants W0 transposed (in,out):
+        a TrainStep engine stores it that way (weight is then a .t() view); otherwise a transposed
+        copy is made for this call when the window path applies."""
+        st = _StepState()
+        st.desc = self._native_desc(training)
+        st.basis = self._basis_desc()
+        tensors = [p.data for p in self._param_list()]
+        w0 = tensors[0]
+        st.keep = None
+        flags = N.FLAG_DENSE if force_dense else 0
+        if not w0.is_contiguous() and w0.t().is_contiguous():
+            tensors[0] = w0.t()                                  # engine-owned (in,out) storage
+            flags |= N.FLAG_W0_T
+        elif not force_dense and N.step_uses_window(st.basis, st.desc, N.FLAG_W0_T):
+            st.keep = w0.t().contiguous()
+            tensors[0] = st.keep
+            flags |= N.FLAG_W0_T
+        st.flags = flags
+        st.w0_transposed = bool(flags & N.FLAG_W0_T)
+        st.params = self._pack(tensors)
+        return st
 
     def build_features(self, X, coords, t, out=None):
         """[X | phi | psi] into a row-padded (B, ld) buffer (ld multiple of 32 floats = 128 B)."""
@@ -279,16 +322,26 @@ class STInterpMLP(nn.Module):
         if not coords.is_cuda:
             raise RuntimeError("stnf (MI355X build): forward() needs tensors on a HIP device "
                                "(config `device: cuda`); there is no CPU path")
-        feats = self.build_features(X, coords, t)
+        coords = coords.contiguous().float()
+        t = t.contiguous().float().view(-1)
+        Xc = None
+        if self.p > 0:
+            if X is None or X.numel() == 0:
+                raise RuntimeError(f"model has p={self.p} covariates but X is empty")
+            Xc = X.contiguous().float()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if need_grad:
-            return _MlpFunction.apply(self, feats, self.training, *self._param_list())
-        B = feats.shape[0]
-        desc = self._native_desc()
-        y = torch.empty(B, self.output_dim, device=feats.device, dtype=torch.float32)
-        ws = torch.empty(N.mlp_workspace_bytes(desc, B) // 4, device=feats.device, dtype=torch.float32)
+            return _StepFunction.apply(self, Xc, coords, t, self.training, *self._param_list())
+        st = self._step_state(coords.device, force_dense=self.force_dense_path, training=self.training)
+        B = coords.shape[0]
+        y = torch.empty(B, self.output_dim, device=coords.device, dtype=torch.float32)
+        if B == 0:
+            return y
+        ws = torch.empty(N.step_workspace_bytes(st.basis, st.desc, B, st.flags) // 4,
+                         device=coords.device, dtype=torch.float32)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.training and self.dropout_p > 0) else 0
-        N.mlp_forward(desc, self._native_tensors(), feats, B, y, ws, self.training, seed)
+        N.forward(st.basis, st.desc, st.params, coords, t, Xc, B, y, ws, st.flags,
+                  training=self.training, seed=seed)
         return y
 
 

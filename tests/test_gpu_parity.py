@@ -152,13 +152,22 @@ def test_rbf_build_unaligned_and_ragged():
 
 
 # ------------------------------------------------------------------ forward / loss / backward
+@pytest.mark.parametrize("path", ["auto", "dense"])
 @pytest.mark.parametrize("name", list(cases.MODEL_CASES))
-def test_forward_backward_matches_reference(name):
+def test_forward_backward_matches_reference(name, path):
+    """path 'auto' takes the index-window kernels where they apply (Wendland/triangular, uniform
+    grid, hidden[0] in {128,256}) and the dense kernels elsewhere; 'dense' forces materialisation."""
+    from stnf import _native as N
     cfg = cases.MODEL_CASES[name]
     g = load(name)
     X, coords, t, y = cases.make_inputs(cfg)
     d = dev()
     m = build_model(cfg)
+    m.force_dense_path = path == "dense"
+    st = m._step_state(d, force_dense=m.force_dense_path)
+    expect_window = (path == "auto" and cfg["basis"] in ("wendland", "triangular")
+                     and cfg["hidden_dims"][0] in (128, 256))
+    assert N.step_uses_window(st.basis, st.desc, st.flags) == expect_window
     m.train()
     Xd, cd, td, yd = (torch.from_numpy(a).to(d) for a in (X, coords, t, y))
     yp = m(Xd, cd, td)
@@ -362,3 +371,173 @@ def test_gemm_f32_layouts(layout, shape):
     # fp32 fma chain: error ~ 1e-7 * sum|a b| ~ 1e-7 * sqrt(K) here
     assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.sqrt(K)) * 4
     assert rel_l2(got, ref) <= 2e-6
+
+
+# ------------------------------------------------------------------ window path: integer bookkeeping
+@pytest.mark.parametrize("B,G", [(1, 8), (257, 16), (4096, 64), (5000, 256)])
+def test_bin_obs_bit_exact(B, G):
+    """cell keys, cell_start and the sorted permutation are integers: bit-exact against the oracle."""
+    from stnf import _native as N
+    rs = np.random.RandomState(B + G)
+    coords = rs.uniform(-0.05, 1.05, (B, 2)).astype(np.float32)
+    coords[: min(B, 4)] = np.array([[0, 0], [1, 1], [0.5, 0.5], [np.nan, 2.0]], np.float32)[: min(B, 4)]
+    if B > 600:
+        coords[100:600] = coords[100]            # a crowded cell: ordering inside a cell is by index
+    keys, cell_start, perm = N.bin_obs(torch.from_numpy(coords).to(dev()), G)
+    ko = orc.cell_keys(coords, G)
+    assert np.array_equal(keys.cpu().numpy(), ko)
+    counts = np.bincount(ko, minlength=G * G)
+    assert np.array_equal(cell_start.cpu().numpy(), np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+    assert np.array_equal(perm.cpu().numpy(), np.argsort(ko, kind="stable").astype(np.int32))
+
+
+@pytest.mark.parametrize("sides,p", [([5, 9, 11], 0), ([32, 64, 72], 3), ([3], 0), ([1, 2, 6, 7], 1),
+                                     ([32, 64, 128, 168], 0)])
+def test_knot_windows_bit_exact(sides, p):
+    from stnf import _native as N
+    rs = np.random.RandomState(sum(sides))
+    coords = rs.uniform(-0.2, 1.2, (3000, 2)).astype(np.float32)
+    coords[:6] = np.array([[0, 0], [1, 1], [0.5, 0.5], [np.nan, 0.3], [np.inf, -np.inf], [1e-8, 1 - 1e-7]],
+                          np.float32)
+    ix0, iy0, col0 = N.knot_windows(torch.from_numpy(coords).to(dev()), sides, p)
+    ox, oy, oc, _ = orc.knot_windows(coords, sides, p)
+    assert np.array_equal(ix0.cpu().numpy(), ox)
+    assert np.array_equal(iy0.cpu().numpy(), oy)
+    assert np.array_equal(col0.cpu().numpy(), oc)
+
+
+# ------------------------------------------------------------------ window path vs dense path
+@pytest.mark.parametrize("name", ["default227", "default227_tri", "c2_b257", "c2_b257_noln"])
+def test_window_and_dense_paths_agree(name):
+    """Same model, both kernel families: predictions and every gradient agree to rounding, and
+    y_pred comes back in the caller's row order."""
+    cfg = cases.MODEL_CASES[name]
+    X, coords, t, y = cases.make_inputs(cfg)
+    d = dev()
+    outs = []
+    for dense in (False, True):
+        m = build_model(cfg)
+        m.force_dense_path = dense
+        m.train()
+        yp = m(*(torch.from_numpy(a).to(d) for a in (X, coords, t)))
+        torch.nn.MSELoss()(yp, torch.from_numpy(y).to(d)).backward()
+        outs.append((yp.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}))
+    (yw, gw), (yd, gd) = outs
+    assert np.abs(yw - yd).max() <= 2e-6 * max(1.0, np.abs(yd).max())
+    for k in gd:
+        assert rel_l2(gw[k], gd[k]) <= 2e-6, k
+
+
+def test_window_path_with_covariates_and_h128():
+    """p > 0 rows of W0^T and the 128-wide first layer, against the float64 oracle."""
+    cfg = dict(p=3, k_spatial_centers=[25, 81, 121], k_temporal_centers=[10, 15, 45],
+               hidden_dims=[128, 64], layernorm=True, basis="wendland", output_dim=1, B=300, seed=51)
+    from stnf import _native as N
+    X, coords, t, y = cases.make_inputs(cfg)
+    d = dev()
+    m = build_model(cfg)
+    st = m._step_state(d)
+    assert N.step_uses_window(st.basis, st.desc, st.flags)
+    params = cases.make_state(cfg)
+    m.train()
+    yp = m(*(torch.from_numpy(a).to(d) for a in (X, coords, t)))
+    loss = torch.nn.MSELoss()(yp, torch.from_numpy(y).to(d))
+    loss.backward()
+    yo, lo, go = orc.train_step_grads(X, coords, t, y, params, cfg)
+    assert np.abs(yp.detach().cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
+    assert abs(loss.item() - lo) <= TOL * lo
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), go[k]) <= TOL, k
+
+
+def test_window_full_batch_sizes():
+    """B = 4096 and 20000 rows of the C2 model on the window path: loss and the gradient's column
+    sums (one per knot: which knots an observation touches) against the float64 oracle."""
+    for B, seed in ((4096, 99), (20000, 98)):
+        cfg = dict(cases.MODEL_CASES["c2_b257"], B=B, seed=seed)
+        X, coords, t, y = cases.make_inputs(cfg)
+        d = dev()
+        m = build_model(cfg)
+        m.train()
+        params = cases.make_state(cfg)
+        yp = m(*(torch.from_numpy(a).to(d) for a in (X, coords, t)))
+        loss = torch.nn.MSELoss()(yp, torch.from_numpy(y).to(d))
+        loss.backward()
+        yo, lo, go = orc.train_step_grads(X, coords, t, y, params, cfg)
+        assert np.abs(yp.detach().cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
+        assert abs(loss.item() - lo) <= TOL * lo
+        for k, p in m.named_parameters():
+            assert rel_l2(p.grad.cpu().numpy(), go[k]) <= TOL, k
+
+
+# ------------------------------------------------------------------ fused engine (TrainStep / Predictor)
+@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("name", ["default227", "c2_b257"])
+def test_engine_steps_match_reference(name, dense):
+    """OPT['steps'] fused steps (window or dense kernels, flat AdamW+clip+EMA, transposed W0
+    storage) against the float64 golden of the reference's batch body; the nn.Module's parameters
+    remain valid views (state_dict shapes unchanged)."""
+    from stnf.engine import TrainStep
+    cfg = cases.MODEL_CASES[name]
+    g = load(name)
+    o = cases.OPT
+    d = dev()
+    m = build_model(cfg)
+    m.train()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    eng = TrainStep(m, lr=o["lr"], weight_decay=o["weight_decay"], betas=o["betas"], eps=o["eps"],
+                    grad_clip=o["grad_clip"], ema_decay=o["ema_decay"], max_batch=cfg["B"], force_dense=dense)
+    assert eng.uses_window == (not dense)
+    losses = []
+    for _ in range(o["steps"]):
+        eng.step(None, coords, t, y)
+        losses.append(eng.mean_loss())
+    assert np.abs(np.array(losses) - g["opt_losses64"]).max() <= 5 * TOL * max(1.0, g["opt_losses64"].max())
+    sd = m.state_dict()
+    for k, p in m.named_parameters():
+        assert tuple(sd[k].shape) == tuple(p.shape)
+        check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=2e-5)
+    # EMA shadow: swap it in and read it through the module's parameters
+    eng.swap_in_ema()
+    for k, p in m.named_parameters():
+        check_vs_digest(p.detach().cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=2e-5)
+    eng.swap_in_ema()
+    # module-level eval forward still works on the engine-owned (transposed) storage
+    m.eval()
+    with torch.no_grad():
+        y1 = m(None, coords, t)
+    assert torch.isfinite(y1).all() and y1.shape == (cfg["B"], 1)
+
+
+def test_engine_graph_replay_equals_eager():
+    from stnf.engine import TrainStep
+    cfg = cases.MODEL_CASES["default227"]
+    d = dev()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    res = []
+    for graph in (False, True):
+        m = build_model(cfg)
+        eng = TrainStep(m, ema_decay=0.99, max_batch=cfg["B"], use_graph=graph)
+        for _ in range(4):
+            eng.step(None, coords, t, y)
+        res.append((eng.mean_loss(), eng.flat.clone()))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
+
+
+def test_predictor_matches_module_forward():
+    from stnf.engine import Predictor
+    cfg = cases.MODEL_CASES["c2_b257"]
+    d = dev()
+    m = build_model(cfg)
+    m.eval()
+    rs = np.random.RandomState(4)
+    n = 5000
+    coords = torch.from_numpy(rs.uniform(0, 1, (n, 2)).astype(np.float32)).to(d)
+    t = torch.from_numpy(rs.uniform(0, 1, (n, 1)).astype(np.float32)).to(d)
+    with torch.no_grad():
+        ref = m(None, coords, t)
+    for dense in (False, True):
+        pr = Predictor(m, chunk=2048, use_graph=True, force_dense=dense)
+        out = pr.predict(coords, t)
+        assert torch.allclose(out, ref, rtol=1e-5, atol=2e-6)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(handle, sym), f"{sym} declared in stdadk.h but not exported"
     assert declared == set(N.exported_symbols()), declared ^ set(N.exported_symbols())
-    assert N.lib().stdadk_abi_version() == 1
+    assert N.lib().stdadk_abi_version() == 2
 
 
 def test_abi_struct_layout_matches_header():
@@ -34,6 +34,8 @@ def test_abi_struct_layout_matches_header():
     # stdadk_mlp_desc: int32 n_hidden, in_dim, hidden[8], out_dim, layernorm; float ln_eps, dropout_p
     assert ctypes.sizeof(N.MlpDesc) == 4 * (2 + 8 + 2 + 2)
     assert ctypes.sizeof(N.MlpTensors) == 8 * (9 + 9 + 8 + 8)
+    # stdadk_basis_desc: 3 + 8 int32 (padded to 48), 2 int64, 4 pointers
+    assert ctypes.sizeof(N.BasisDesc) == 48 + 16 + 32
     d = N.make_desc(297, [256, 256, 128], 1, True, 0.1)
     assert N.lib().stdadk_mlp_workspace_bytes(ctypes.byref(d), 4096) > 4096 * (256 + 256 + 128) * 2 * 4
     bad = N.make_desc(297, [2000], 1, True, 0.0)
