@@ -172,14 +172,16 @@ def main():
                                                 model.temporal_basis.bandwidths, feats), 50)
         rbf_bytes = B * (12 + 4 * D)                         # 12 B read + 4*D written / obs
         rbf_gbs = rbf_bytes / t_rbf / 1e9
-        W1 = model.mlp[0].weight
+        # layer-1 dense GEMMs on the engine's (in,out) weight storage: z = F W0^T-stored, dW0^T = F^T dz
+        W0T = model.mlp[0].weight.t()
+        assert W0T.is_contiguous()
         z = torch.empty(B, H[0], device=dev)
         wsg = torch.empty(max(N.lib().stdadk_gemm_workspace_bytes(B, H[0], D),
-                              N.lib().stdadk_gemm_workspace_bytes(H[0], D, B), 4) // 4, device=dev)
-        t_g1 = time_events(lambda: N.gemm(feats, False, W1, False, B, H[0], D, out=z, workspace=wsg), 20)
+                              N.lib().stdadk_gemm_workspace_bytes(D, H[0], B), 4) // 4, device=dev)
+        t_g1 = time_events(lambda: N.gemm(feats, False, W0T, True, B, H[0], D, out=z, workspace=wsg), 20)
         g1_tflops = 2.0 * B * D * H[0] / t_g1 / 1e12
-        dW = torch.empty(H[0], D, device=dev)
-        t_dw = time_events(lambda: N.gemm(z, True, feats, True, H[0], D, B, out=dW, workspace=wsg), 20)
+        dW = torch.empty(D, H[0], device=dev)
+        t_dw = time_events(lambda: N.gemm(feats, True, z, True, D, H[0], B, out=dW, workspace=wsg), 20)
         dw_tflops = 2.0 * B * D * H[0] / t_dw / 1e12
         dom = max((("gemm_f32 layer-1 forward (z1 = F W1^T)", t_g1, g1_tflops),
                    ("gemm_f32 layer-1 dW (dW1 = dz1^T F)", t_dw, dw_tflops)), key=lambda r: r[1])

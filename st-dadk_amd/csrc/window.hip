@@ -105,11 +105,16 @@ __global__ void cell_order_kernel(const int *__restrict__ cell_start, int ncell,
   }
 }
 
+__global__ void zero_ints_kernel(int *__restrict__ p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 int bin_obs(const float *coords, const float *t, const float *y, int Q, const float *X, int p, int B,
             int G, const BinBuffers &bb, hipStream_t st) {
   const int ncell = G * G;
-  hipError_t e = hipMemsetAsync(bb.hist, 0, sizeof(int) * ncell, st);
-  if (e != hipSuccess) { set_error("bin_obs: memset: %s", hipGetErrorString(e)); return (int)e; }
+  // a kernel, not hipMemsetAsync: the step must stay a pure chain of kernel nodes under capture
+  hipLaunchKernelGGL(zero_ints_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st, bb.hist, ncell);
   const unsigned nb = (unsigned)ceil_div(B, 256);
   hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, coords, B, G, bb.keys, bb.hist);
   hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, bb.hist, ncell, bb.cell_start, bb.cursor);
@@ -320,9 +325,15 @@ static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
   const int Kt_pad = (a.g.Kt + 3) & ~3;
   size_t lds = ((size_t)a.g.Kt * 64 * CPL + (FW_T / 64) * (LIST * 2 + Kt_pad)) * sizeof(float);
   auto kern = l1_window_fwd_kernel<CPL, LN, BASIS>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) { set_error("l1_window_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  // raise the dynamic-LDS cap once per process and kernel (never inside a stream capture: the
+  // engine runs its first step eagerly); 160 KiB is the CU's whole LDS
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("l1_window_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)a.n_wg), dim3(FW_T), lds, st, a);
   STDADK_CHECK_LAUNCH("l1_window_forward");
   return 0;

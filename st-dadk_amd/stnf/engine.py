@@ -103,6 +103,7 @@ class TrainStep:
         self._graph = None
         self._g_in = None
         self._g_B = None
+        self._warm = False
 
     # ------------------------------------------------------------------------------------
     def set_lr(self, lr):
@@ -149,6 +150,12 @@ class TrainStep:
         self.rows_seen += B
 
     def _step_graph(self, X, coords, t, y, B, global_rows):
+        if not self._warm:
+            # the first step runs eagerly: HIP loads code objects and applies the kernels' LDS
+            # attributes on first launch, neither of which may happen inside a stream capture
+            self._warm = True
+            self._enqueue(X, coords, t, y, B, global_rows)
+            return
         if self._graph is None or self._g_B != (B, global_rows):
             p = self.model.p
             self._g_in = (torch.empty(B, p, device=self.dev) if p > 0 else None,
@@ -157,7 +164,6 @@ class TrainStep:
             self._g_B = (B, global_rows)
             # AdamW and the dropout generator read lr / step from device scalars, so a replay
             # advances them; capture itself executes nothing
-            self.step_dev.fill_(self.step_count)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -201,6 +207,7 @@ class Predictor:
                                                      self.state.flags) // 4, device=self.dev)
         self.use_graph = use_graph
         self._graph = None
+        self._warm = False
         self._in = (torch.empty(self.chunk, 2, device=self.dev), torch.empty(self.chunk, device=self.dev))
         self._out = torch.empty(self.chunk, model.output_dim, device=self.dev)
 
@@ -219,7 +226,10 @@ class Predictor:
         out = torch.empty(n, self.model.output_dim, device=self.dev)
         for s in range(0, n, self.chunk):
             B = min(self.chunk, n - s)
-            if self.use_graph and B == self.chunk:
+            if self.use_graph and B == self.chunk and not self._warm:
+                self._warm = True           # first full chunk eagerly (see TrainStep._step_graph)
+                self._enqueue(coords[s:s + B], t[s:s + B], out[s:s + B], B)
+            elif self.use_graph and B == self.chunk:
                 if self._graph is None:
                     torch.cuda.synchronize()
                     self._graph = torch.cuda.CUDAGraph()
