@@ -3,11 +3,16 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload c2|default|c4]
 
-One "step" = one optimisation step on one mini-batch of synthetic KAUST-shaped observations:
-feature build (multi-resolution Wendland + Gaussian bases) -> MLP forward -> MSE -> backward ->
-(all-reduce) -> clip + AdamW + EMA, everything resident in HBM.  N > 1 is launched by
-torch.distributed.run, one rank per GPU, observation-sharded with one RCCL all-reduce of the flat
-gradient per step (weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+One "step" = one optimisation step on one mini-batch of synthetic KAUST-shaped observations resident
+in HBM: feature build (multi-resolution Wendland + Gaussian bases) -> MLP forward -> MSE -> backward
+-> (all-reduce) -> clip + AdamW + EMA.  N > 1 is launched by torch.distributed.run, one rank per GPU,
+observation-sharded with one RCCL all-reduce of the flat gradient per step (weak scaling: per-GPU
+batch fixed).  Rank 0 prints ONE JSON line:
+  value      whole-job observations/s over the K timed steps (max over ranks, barrier-bracketed)
+  roofline   the dominant kernel of the timed step: average launch duration measured live with HIP
+             events on the launch stream (stdadk_profile_*), algorithmic bytes/flops per launch
+  rbf_build  the standalone materialising feature builder (the "RBF-build GB/s" of BASELINE.json)
+  cpu_baseline  the oracle's torch-CPU port of the reference's batch body on this box's host cores
 """
 import argparse
 import json
@@ -35,7 +40,7 @@ WORKLOADS = {
                hidden_dims=[256, 256, 128], n_obs=1_000_000, name="C4 synthetic 1M obs, 4-res 49728 knots"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 
 def synth(n, seed, device):
@@ -62,14 +67,27 @@ def time_events(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters * 1e-3      # seconds per call
 
 
-def cpu_baseline(wl, batch, dropout, budget_s=15.0):
+def host_cores():
+    """CPU threads this process may really use: cgroup quota if set, else affinity, capped at the
+    box's per-GPU CPU share (16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(wl, batch, dropout, budget_s=20.0):
     """The oracle's torch-CPU port of the reference batch body, timed on this box's host cores on a
     bounded sample (a few steps of the same batch size)."""
     from oracle import torch_port as tp
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     cfg = dict(p=0, k_spatial_centers=wl["k_spatial_centers"], k_temporal_centers=wl["k_temporal_centers"],
                hidden_dims=wl["hidden_dims"], layernorm=True, dropout=dropout, basis="wendland", output_dim=1)
@@ -86,15 +104,35 @@ def cpu_baseline(wl, batch, dropout, budget_s=15.0):
         if el > budget_s or n >= 50:
             break
     return dict(value=batch * n / el, unit="obs/s", cores=cores, kind="port",
-                sample=f"{n} train steps of batch {batch} (oracle/torch_port.py, same model/config, "
-                       f"{el:.1f} s of CPU work)")
+                sample=f"{n} train steps of batch {batch} (oracle/torch_port.py: the reference's op sequence, "
+                       f"same model/config/optimizer, {el:.1f} s of CPU work, {cores} torch threads)")
+
+
+def kernel_work(name, B, D, H, P_flat, nnz_pairs, Kt):
+    """Algorithmic work of one launch of a library kernel: (bound, amount, unit) or None.
+    HBM kernels are priced in bytes that MUST cross HBM, MFMA kernels in flops of the mathematical
+    product (DESIGN.md 'kernels')."""
+    if name.startswith("adamw_ema_kernel"):
+        return "hbm", 36.0 * P_flat, "B"            # read p,g,m,v,ema + write p,m,v,ema (4 B each)
+    if name.startswith("sumsq_kernel"):
+        return "hbm", 4.0 * P_flat, "B"
+    if "rbf_build_kernel" in name:
+        return "hbm", B * (12.0 + 4.0 * D), "B"
+    if "l1_window_bwd_kernel" in name:
+        return "mfma", 2.0 * nnz_pairs * H[0], "flop"    # dW0^T rows: one fma per non-zero (obs,knot) x H
+    if "l1_window_fwd_kernel" in name:
+        return "mfma", 2.0 * (nnz_pairs + B * Kt) * H[0], "flop"
+    if name.startswith("gemm_f32_kernel") and "M=" in name:
+        f = dict(kv.split("=") for kv in name.split() if "=" in kv)
+        return "mfma", 2.0 * int(f["M"]) * int(f["N"]) * int(f["K"]), "flop"
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU mini-batch (reference YAML: 4096)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--dropout", type=float, default=0.1)
@@ -163,28 +201,65 @@ def main():
     if rank == 0:
         D = model.input_dim
         H = wl["hidden_dims"]
-        # ---- roofline of the dominant kernels, measured live with HIP events on the launch stream
+        Kt = model.k_temporal
         c, tt, yy = batch(0)
+        c, tt, yy = c.contiguous(), tt.contiguous().view(-1), yy.contiguous()
+        # ---- per-kernel device time of the step, live, with HIP events on the launch stream
+        n_prof = 10
+        N.profile_enable(True)
+        for _ in range(n_prof):
+            eng._enqueue(None, c, tt, yy, B, B * world)
+        recs = N.profile_collect()
+        N.profile_enable(False)
+        agg = {}
+        for name, ms in recs:
+            a = agg.setdefault(name, [0, 0.0])
+            a[0] += 1
+            a[1] += ms
+        per_step = sorted(((nm, cnt / n_prof, tot / cnt * 1e3, tot / n_prof * 1e3) for nm, (cnt, tot) in agg.items()),
+                          key=lambda r: -r[3])      # (name, launches/step, avg us, us/step)
+        kernels_us = {nm.replace("(", "").replace(")", "")[:80]: round(us, 2) for nm, _, _, us in per_step}
+        # exact count of non-zero (observation, knot) pairs of this batch, for the window kernels
+        phi = model.spatial_basis(c)
+        nnz = int((phi != 0).sum().item())
+        del phi
+        P_flat = eng.flat.numel()
+        dom = None
+        for nm, lps, avg_us, us in per_step:
+            w = kernel_work(nm.replace("(stdadk::", "").replace("(", ""), B, D, H, P_flat, nnz, Kt)
+            if w is not None:
+                dom = (nm, avg_us, w)
+                break
+        roof = None
+        if dom:
+            nm, avg_us, (bound, amount, _) = dom
+            if bound == "hbm":
+                ach = amount / (avg_us * 1e-6) / 1e9
+                roof = {"kernel": nm, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_us,
+                        "algorithmic_bytes_per_launch": amount}
+            else:
+                ach = amount / (avg_us * 1e-6) / 1e12
+                roof = {"kernel": nm, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "avg_launch_us": avg_us, "algorithmic_flops_per_launch": amount}
+            tr_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tr_file):           # HBM bytes/launch from rocprofv3 --pmc (committed summary)
+                try:
+                    tj = json.load(open(tr_file))
+                    for key, val in tj.get("kernels", {}).items():
+                        if key in nm:
+                            roof["traffic"] = val
+                except Exception:
+                    pass
+        # ---- the standalone materialising feature builder ("RBF-build GB/s")
         feats = torch.empty(B, (D + 31) // 32 * 32, device=dev)
-        t_rbf = time_events(lambda: N.rbf_build(c.contiguous(), tt.contiguous().view(-1), None,
-                                                model.spatial_basis.centers, model.spatial_basis._bandwidths,
-                                                "wendland", model.temporal_basis.centers,
-                                                model.temporal_basis.bandwidths, feats), 50)
+        t_rbf = time_events(lambda: N.rbf_build(c, tt, None, model.spatial_basis.centers,
+                                                model.spatial_basis._bandwidths, "wendland",
+                                                model.temporal_basis.centers, model.temporal_basis.bandwidths,
+                                                feats), 50)
         rbf_bytes = B * (12 + 4 * D)                         # 12 B read + 4*D written / obs
         rbf_gbs = rbf_bytes / t_rbf / 1e9
-        # layer-1 dense GEMMs on the engine's (in,out) weight storage: z = F W0^T-stored, dW0^T = F^T dz
-        W0T = model.mlp[0].weight.t()
-        assert W0T.is_contiguous()
-        z = torch.empty(B, H[0], device=dev)
-        wsg = torch.empty(max(N.lib().stdadk_gemm_workspace_bytes(B, H[0], D),
-                              N.lib().stdadk_gemm_workspace_bytes(D, H[0], B), 4) // 4, device=dev)
-        t_g1 = time_events(lambda: N.gemm(feats, False, W0T, True, B, H[0], D, out=z, workspace=wsg), 20)
-        g1_tflops = 2.0 * B * D * H[0] / t_g1 / 1e12
-        dW = torch.empty(D, H[0], device=dev)
-        t_dw = time_events(lambda: N.gemm(feats, True, z, True, D, H[0], B, out=dW, workspace=wsg), 20)
-        dw_tflops = 2.0 * B * D * H[0] / t_dw / 1e12
-        dom = max((("gemm_f32 layer-1 forward (z1 = F W1^T)", t_g1, g1_tflops),
-                   ("gemm_f32 layer-1 dW (dW1 = dz1^T F)", t_dw, dw_tflops)), key=lambda r: r[1])
         out = {
             "metric": "train-step samples/sec (obs points/sec)", "value": args.gpus * B * args.steps / el,
             "unit": "obs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -196,13 +271,13 @@ def main():
                        "path": ("index-window layer 1 (compact support) + fp32 MFMA MLP" if eng.uses_window
                                 else "materialised features + dense fp32 MFMA MLP"),
                        "hipgraph": bool(eng.use_graph), "parallelism": f"dp{args.gpus}"},
-            "roofline": {"kernel": dom[0], "bound": "mfma", "achieved": dom[2], "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": dom[2] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                         "ms": dom[1] * 1e3},
+            "roofline": roof,
             "rbf_build": {"bound": "hbm", "achieved": rbf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": rbf_gbs / HBM_PEAK_GBS, "bytes_per_obs": 12 + 4 * D, "ms": t_rbf * 1e3,
-                          "traffic": None},
-            "kernels_ms": {"rbf_build": t_rbf * 1e3, "gemm_l1_fwd": t_g1 * 1e3, "gemm_l1_dW": t_dw * 1e3},
+                          "frac": rbf_gbs / HBM_PEAK_GBS, "bytes_per_obs": 12 + 4 * D, "avg_launch_us": t_rbf * 1e6,
+                          "traffic": None, "note": "both launches of stdadk_rbf_build_f32 (spatial tiles + tail tile)"},
+            "kernels_us_per_step": kernels_us,
+            "kernel_time_us_per_step": round(sum(r[3] for r in per_step), 1),
+            "nonzero_obs_knot_pairs_per_obs": nnz / B,
             "final_mean_loss": loss,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:

@@ -31,6 +31,7 @@ extern "C" {
 #define STDADK_ABI_VERSION 2
 #define STDADK_MAX_HIDDEN 8
 #define STDADK_MAX_LEVELS 8
+#define STDADK_SUMSQ_PARTS 256 /* partial sums written by stdadk_sumsq_f32 */
 
 #define STDADK_E_ARG (-1)     /* null pointer / negative size / bad enum       */
 #define STDADK_E_SHAPE (-2)   /* shapes inconsistent with the descriptor      */
@@ -117,22 +118,26 @@ int stdadk_mse_f32(const float *y_pred, const float *y, int64_t n, float grad_sc
 /* ------------------------------------------------------------------------------------------
  * A9  clip_grad_norm_ + AdamW + EMA on flat fp32 buffers of n elements
  * (scripts/train_st_interp.py:696-712, stnf/utils/ema.py:52-66, torch.optim.AdamW).
- *   stdadk_sumsq_f32 :  out[0] += sum(g^2)      (out zeroed by the caller; after an all-reduce of
- *                       the gradients this is the post-reduce global norm the clip must use)
- *   stdadk_adamw_ema_f32: coef = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) if max_norm > 0 else 1
+ *   stdadk_sumsq_f32 : parts[0..STDADK_SUMSQ_PARTS) = partial sums of g^2 (all entries written, fixed
+ *                      order => reproducible; several tensors may each fill their own block of
+ *                      partials).  After an all-reduce of the gradients this gives the post-reduce
+ *                      global norm the clip must use.
+ *   stdadk_adamw_ema_f32: ss = sum(sumsq_parts[0..n_parts));
+ *       coef = min(1, max_norm/(sqrt(ss)+1e-6)) if max_norm > 0 else 1
  *       g' = g*coef*grad_mul; p *= 1-lr*wd; m = b1*m+(1-b1)*g'; v = b2*v+(1-b2)*g'^2;
  *       p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps);
  *       ema = decay*ema + (1-decay)*p   (skipped when ema == NULL)
  *   lr is read from the device scalar lr_dev[0] when non-NULL (graph-replayable schedules),
- *   else from `lr`.  `step` is the 1-based step count (host value) or read from step_dev[0]
- *   (int32, incremented by the kernel) when non-NULL.
+ *   else from `lr`.  `step` is the 1-based step count (host value); when step_dev (device
+ *   int32[2], both zero-initialised: [0] completed steps, [1] scratch) is non-NULL the kernel uses
+ *   step_dev[0]+1 and stores it back when the update has finished.
  * ------------------------------------------------------------------------------------------ */
-int stdadk_sumsq_f32(const float *g, int64_t n, float *out, stdadk_stream_t stream);
+int stdadk_sumsq_f32(const float *g, int64_t n, float *parts, stdadk_stream_t stream);
 
 int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
                          float lr, const float *lr_dev, float beta1, float beta2, float eps,
                          float weight_decay, int32_t step, int32_t *step_dev, float max_norm,
-                         const float *sumsq, float grad_mul, float ema_decay,
+                         const float *sumsq_parts, int32_t n_parts, float grad_mul, float ema_decay,
                          stdadk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -195,7 +200,7 @@ int stdadk_backward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *m
 /* A2-A8 in one call: training forward, nn.MSELoss and its gradient, backward:
  *   loss_sum[0] += sum((y_pred-y)^2);  grads = d/dparams of grad_scale * sum((y_pred-y)^2)
  * (grad_scale = 1/(rows*Q) of the GLOBAL batch, so summing the ranks' gradients gives the global
- * mean).  y [B,Q]; y_pred [B,Q] is written (caller's row order). */
+ * mean).  y [B,Q]; y_pred [B,Q] (caller's row order) is optional: NULL skips writing it. */
 int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
                              const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,
                              const float *coords, const float *t, const float *X, const float *y,
@@ -232,6 +237,16 @@ size_t stdadk_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int stdadk_gemm_f32(const float *A, int64_t lda, int32_t a_km, const float *B, int64_t ldb,
                     int32_t b_km, int32_t M, int32_t N, int32_t K, const float *bias, float *C,
                     int64_t ldc, void *workspace, size_t workspace_bytes, stdadk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid: when enabled, every kernel the library launches is bracketed by two HIP events
+ * on its launch stream.  stdadk_profile_collect synchronises them and writes one "name\tms\n" line
+ * per launch (launch order) into buf; it returns the bytes needed including the terminator (call
+ * again with a bigger buffer if that exceeds cap).  Enabling clears earlier records.  Not for use
+ * under stream capture; host-side, single-threaded.
+ * ------------------------------------------------------------------------------------------ */
+int stdadk_profile_enable(int32_t on);
+int64_t stdadk_profile_collect(char *buf, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,12 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
 #include "../../include/stdadk.h"
 
 namespace stdadk {
@@ -12,7 +18,47 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- per-launch HIP-event profiler (off by default; not thread-safe, one stream at a time)
+bool g_prof_on = false;
+struct ProfRec { std::string name; hipEvent_t e0, e1; };
+static std::vector<ProfRec> g_recs;
+
+void prof_before(const char *name, hipStream_t st) {
+  ProfRec r;
+  r.name = name;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  hipEventRecord(r.e0, st);
+  g_recs.push_back(r);
+}
+void prof_after(hipStream_t st) {
+  if (!g_recs.empty()) hipEventRecord(g_recs.back().e1, st);
+}
 }  // namespace stdadk
+
+extern "C" int stdadk_profile_enable(int32_t on) {
+  for (auto &r : stdadk::g_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  stdadk::g_recs.clear();
+  stdadk::g_prof_on = on != 0;
+  return 0;
+}
+
+// Synchronises the recorded events and writes "name\tms\n" lines (launch order) into buf.
+// Returns the number of bytes needed (call again with a bigger buffer if > cap), or < 0 on error.
+extern "C" int64_t stdadk_profile_collect(char *buf, int64_t cap) {
+  std::string out;
+  for (auto &r : stdadk::g_recs) {
+    if (hipEventSynchronize(r.e1) != hipSuccess) return STDADK_E_ARG;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return STDADK_E_ARG;
+    char line[32];
+    snprintf(line, sizeof(line), "\t%.6f\n", ms);
+    out += r.name;
+    out += line;
+  }
+  if (buf && cap > (int64_t)out.size()) memcpy(buf, out.c_str(), out.size() + 1);
+  return (int64_t)out.size() + 1;
+}
 
 extern "C" int stdadk_abi_version(void) { return STDADK_ABI_VERSION; }
 extern "C" const char *stdadk_last_error(void) { return stdadk::g_err; }

@@ -28,6 +28,25 @@ void set_error(const char *fmt, ...);
     }                                                                         \
   } while (0)
 
+// Every kernel launch goes through this macro so that stdadk_profile_enable() can bracket it with
+// HIP events on the launch stream (per-kernel device time without an external profiler).
+void prof_before(const char *name, hipStream_t st);
+void prof_after(hipStream_t st);
+extern bool g_prof_on;
+#define STDADK_LAUNCH(kern, grid, block, lds, st, ...)                         \
+  do {                                                                        \
+    if (::stdadk::g_prof_on) ::stdadk::prof_before(#kern, (st));              \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);              \
+    if (::stdadk::g_prof_on) ::stdadk::prof_after((st));                      \
+  } while (0)
+
+#define STDADK_LAUNCH_NAMED(name, kern, grid, block, lds, st, ...)              \
+  do {                                                                        \
+    if (::stdadk::g_prof_on) ::stdadk::prof_before((name), (st));             \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);              \
+    if (::stdadk::g_prof_on) ::stdadk::prof_after((st));                      \
+  } while (0)
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -248,7 +248,11 @@ int gemm_pick_splits(int M, int N, int K, int *kps, bool big) {
 template <int BM, int BN, bool A_KM, bool B_KM>
 static void launch_v(const GemmArgs &g, int va, int vb, hipStream_t st) {
   dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)g.splits);
-#define L(VA_, VB_) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KM, B_KM, VA_, VB_>), grid, dim3(GT), 0, st, g)
+  char name[96] = "gemm_f32_kernel";
+  if (g_prof_on)
+    snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%d,%s%s> M=%d N=%d K=%d splits=%d", BM, BN,
+             A_KM ? "T" : "N", B_KM ? "N" : "T", g.M, g.N, g.K, g.splits);
+#define L(VA_, VB_) STDADK_LAUNCH_NAMED(name, (gemm_f32_kernel<BM, BN, A_KM, B_KM, VA_, VB_>), grid, dim3(GT), 0, st, g)
   if (va == 4 && vb == 4) L(4, 4);
   else if (va == 4 && vb == 2) L(4, 2);
   else if (va == 4 && vb == 1) L(4, 1);
@@ -317,7 +321,7 @@ int gemm_run(const float *A, int64_t lda, bool a_km, const float *Bm, int64_t ld
   if (rc) return rc;
   if (g.splits > 1 && !keep_slabs) {
     int64_t n = (int64_t)M * N;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, slab,
+    STDADK_LAUNCH(slab_sum_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, slab,
                        g.splits, g.slab_stride, n, bias, N, C, ldc);
     STDADK_CHECK_LAUNCH("slab_sum");
   }

@@ -264,25 +264,29 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_bwd_kernel(
 // Column sums of per-workgroup partials: out_q[c] = sum_blk part[blk*stride + q*seg + c], q < nseg.
 // 64 columns x 4 block-quarters per workgroup, LDS reduction over the quarters.
 struct ColsumOut { float *o[3]; };
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ part, int64_t nblk,
-                                                     int64_t stride, int seg, int nseg, ColsumOut out) {
-  __shared__ float red[4][64];
+constexpr int CS_G = 16;   // block-groups per workgroup
+__global__ __launch_bounds__(64 * CS_G) void colsum_kernel(const float *__restrict__ part, int64_t nblk,
+                                                           int64_t stride, int seg, int nseg,
+                                                           ColsumOut out) {
+  __shared__ float red[CS_G][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
   const int n = seg * nseg;
   float s0 = 0.f, s1 = 0.f;
   if (c < n) {
     int64_t b = ty;
-    for (; b + 4 < nblk; b += 8) {
+    for (; b + CS_G < nblk; b += 2 * CS_G) {
       s0 += part[b * stride + c];
-      s1 += part[(b + 4) * stride + c];
+      s1 += part[(b + CS_G) * stride + c];
     }
-    for (; b < nblk; b += 4) s0 += part[b * stride + c];
+    for (; b < nblk; b += CS_G) s0 += part[b * stride + c];
   }
   red[ty][tx] = s0 + s1;
   __syncthreads();
   if (ty == 0 && c < n) {
-    float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < CS_G; ++g) v += red[g][tx];
     int q = c / seg;
     out.o[q][c - q * seg] = v;
   }
@@ -353,20 +357,22 @@ __global__ __launch_bounds__(ROW_T) void head_bwd_kernel(const float *__restrict
 }
 
 // sum the head partials [blk][Q][h+1] and split them into dW[Q][h] and db[Q]
-__global__ __launch_bounds__(256) void head_reduce_kernel(const float *__restrict__ part, int64_t nblk, int Q,
-                                                          int h, float *__restrict__ dW,
-                                                          float *__restrict__ db) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(64 * CS_G) void head_reduce_kernel(const float *__restrict__ part, int64_t nblk,
+                                                                int Q, int h, float *__restrict__ dW,
+                                                                float *__restrict__ db) {
+  __shared__ float red[CS_G][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + tx;
   const int n = Q * (h + 1);
   float s = 0.f;
   if (i < n)
-    for (int64_t b = ty; b < nblk; b += 4) s += part[b * n + i];
+    for (int64_t b = ty; b < nblk; b += CS_G) s += part[b * n + i];
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && i < n) {
-    float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < CS_G; ++g) v += red[g][tx];
     int q = i / (h + 1), c = i - q * (h + 1);
     if (c < h) dW[q * h + c] = v; else db[q] = v;
   }
@@ -454,7 +460,7 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
     const uint8_t *mk = (c.masks && c.dp > 0.f) ? c.masks[l] : nullptr;
     dim3 grid((unsigned)ceil_div(B, ROW_T / 64));
 #define FWD(LN_, CPL_)                                                                                   \
-  hipLaunchKernelGGL((ln_relu_fwd_kernel<LN_, CPL_>), grid, dim3(ROW_T), 0, st, zsrc, splits,            \
+  STDADK_LAUNCH((ln_relu_fwd_kernel<LN_, CPL_>), grid, dim3(ROW_T), 0, st, zsrc, splits,            \
                      (int64_t)B * h, P->b[l], LN_ ? P->ln_g[l] : (const float *)nullptr,                 \
                      LN_ ? P->ln_b[l] : (const float *)nullptr, d->ln_eps, B, h, xh, ws + pl.rstd[l],    \
                      act, c.dp, c.seed, c.step_dev, l, mk)
@@ -467,7 +473,7 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
   const int L = d->n_hidden, Q = d->out_dim;
   STDADK_REQUIRE(P->W[L] && P->b[L], STDADK_E_ARG, "mlp_forward: output layer weights NULL");
   if (Q <= HEAD_MAXQ && ld_in == K) {
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)ceil_div(B, ROW_T / 64)), dim3(ROW_T), 0, st, in, B,
+    STDADK_LAUNCH(head_fwd_kernel, dim3((unsigned)ceil_div(B, ROW_T / 64)), dim3(ROW_T), 0, st, in, B,
                        K, P->W[L], P->b[L], Q, y_pred);
     STDADK_CHECK_LAUNCH("head_fwd");
   } else {
@@ -498,11 +504,11 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
   const int hL = L > 0 ? d->hidden[L - 1] : d->in_dim;
   STDADK_REQUIRE(G->W[L] && G->b[L], STDADK_E_ARG, "mlp_backward: output layer grads NULL");
   if (Q <= HEAD_MAXQ && L > 0) {
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)nblk), dim3(ROW_T), sizeof(float) * rows * Q, st, aL, dY,
+    STDADK_LAUNCH(head_bwd_kernel, dim3((unsigned)nblk), dim3(ROW_T), sizeof(float) * rows * Q, st, aL, dY,
                        B, hL, P->W[L], Q, dA, part, rows);
     STDADK_CHECK_LAUNCH("head_bwd");
     int n = Q * (hL + 1);
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, part, nblk, Q, hL,
+    STDADK_LAUNCH(head_reduce_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64 * CS_G), 0, st, part, nblk, Q, hL,
                        G->W[L], G->b[L]);
     STDADK_CHECK_LAUNCH("head_reduce");
   } else {
@@ -510,7 +516,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     rc = gemm_run(dY, Q, true, aL, ldaL, true, Q, hL, (int)B, nullptr, G->W[L], hL, slab, false, nullptr, st);
     if (rc) return rc;
     ColsumOut co; co.o[0] = G->b[L]; co.o[1] = co.o[2] = nullptr;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(Q, 64)), dim3(256), 0, st, dY, B, (int64_t)Q, Q, 1, co);
+    STDADK_LAUNCH(colsum_kernel, dim3((unsigned)ceil_div(Q, 64)), dim3(64 * CS_G), 0, st, dY, B, (int64_t)Q, Q, 1, co);
     STDADK_CHECK_LAUNCH("colsum");
     if (L > 0) {
       rc = gemm_run(dY, Q, false, P->W[L], hL, true, (int)B, hL, Q, nullptr, dA, hL, slab, false, nullptr, st);
@@ -523,7 +529,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     const uint8_t *mk = (c.masks && c.dp > 0.f) ? c.masks[l] : nullptr;
     STDADK_REQUIRE(G->W[l] && G->b[l], STDADK_E_ARG, "mlp_backward: layer %d grads NULL", l);
 #define BWD(LN_, CPL_)                                                                                   \
-  hipLaunchKernelGGL((ln_relu_bwd_kernel<LN_, CPL_>), dim3((unsigned)nblk), dim3(ROW_T), 0, st, dA,      \
+  STDADK_LAUNCH((ln_relu_bwd_kernel<LN_, CPL_>), dim3((unsigned)nblk), dim3(ROW_T), 0, st, dA,      \
                      ws + pl.xhat[l], ws + pl.rstd[l], LN_ ? P->ln_g[l] : (const float *)nullptr,        \
                      LN_ ? P->ln_b[l] : (const float *)nullptr, B, h, dZ, part, c.dp, c.seed,            \
                      c.step_dev, l, mk, rows)
@@ -535,11 +541,11 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     if (d->layernorm) {
       STDADK_REQUIRE(G->ln_g[l] && G->ln_b[l], STDADK_E_ARG, "mlp_backward: layer %d LN grads NULL", l);
       co.o[0] = G->ln_g[l]; co.o[1] = G->ln_b[l]; co.o[2] = G->b[l];
-      hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(3 * h, 64)), dim3(256), 0, st, part, nblk,
+      STDADK_LAUNCH(colsum_kernel, dim3((unsigned)ceil_div(3 * h, 64)), dim3(64 * CS_G), 0, st, part, nblk,
                          (int64_t)3 * h, h, 3, co);
     } else {
       co.o[0] = G->b[l]; co.o[1] = co.o[2] = nullptr;
-      hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(h, 64)), dim3(256), 0, st, part + 2 * h, nblk,
+      STDADK_LAUNCH(colsum_kernel, dim3((unsigned)ceil_div(h, 64)), dim3(64 * CS_G), 0, st, part + 2 * h, nblk,
                          (int64_t)3 * h, h, 1, co);
     }
     STDADK_CHECK_LAUNCH("colsum");
@@ -565,7 +571,7 @@ static int launch_mse(const float *yp, const float *y, int64_t n, float scale, f
                       hipStream_t st) {
   int64_t blocks = ceil_div(n, 256);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, st, yp, y, n, scale, dY, loss_sum);
+  STDADK_LAUNCH(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, st, yp, y, n, scale, dY, loss_sum);
   STDADK_CHECK_LAUNCH("mse");
   return 0;
 }
@@ -740,16 +746,19 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
 }
 
 // forward of one batch; training != 0 keeps everything backward needs in the workspace
+// (window path: `y`, when given, is carried into sorted order next to the observations, and the
+//  predictions stay in sorted order in the plan's ypred buffer; y_pred NULL skips the un-permute)
 static int step_forward(Ctx &c, const stdadk_basis_desc *b, bool window, const float *coords, const float *t,
-                        const float *X, float *y_pred, stdadk_stream_t stream) {
+                        const float *X, const float *y, float *y_pred, stdadk_stream_t stream) {
   const stdadk_mlp_desc *d = c.d;
   float *ws = c.ws;
   int rc;
   if (window) {
-    rc = window_layer0_forward(c, b, coords, t, X, nullptr);
+    rc = window_layer0_forward(c, b, coords, t, X, y);
     if (rc) return rc;
     rc = run_forward(c, 1, ws + c.pl.act[0], d->hidden[0], d->hidden[0], ws + c.pl.ypred);
     if (rc) return rc;
+    if (!y_pred) return 0;
     return unpermute_rows(ws + c.pl.ypred, (const int *)(ws + c.pl.perm), (int)c.B, d->out_dim, y_pred, c.st);
   }
   rc = stdadk_rbf_build_f32(coords, t, X, c.B, b->p, b->s_centers, b->s_bw, b->Ks, b->basis, b->t_centers,
@@ -759,16 +768,18 @@ static int step_forward(Ctx &c, const stdadk_basis_desc *b, bool window, const f
 }
 
 // backward of the batch whose training forward left its state in the workspace; dY in caller order
-static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const float *dY) {
+// (`dY_sorted`: window path only — dY is already the plan's dY buffer in sorted order)
+static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const float *dY, bool dY_sorted) {
   const stdadk_mlp_desc *d = c.d;
   float *ws = c.ws;
   int rc;
   if (!window) return run_backward(c, dY, ws + c.pl.feats, c.pl.ldf, true);
   const int H = d->hidden[0], Q = d->out_dim;
-  // dY rows into sorted order
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(c.B * Q, 256)), dim3(256), 0, c.st, dY,
-                     (const int *)(ws + c.pl.perm), (int)c.B, Q, ws + c.pl.dY);
-  STDADK_CHECK_LAUNCH("gather_rows");
+  if (!dY_sorted) {   // dY rows into sorted order
+    STDADK_LAUNCH(gather_rows_kernel, dim3((unsigned)ceil_div(c.B * Q, 256)), dim3(256), 0, c.st, dY,
+                       (const int *)(ws + c.pl.perm), (int)c.B, Q, ws + c.pl.dY);
+    STDADK_CHECK_LAUNCH("gather_rows");
+  }
   rc = run_backward(c, ws + c.pl.dY, nullptr, 0, false);
   if (rc) return rc;
   // dW0^T: spatial rows by the knot-block owners, temporal / covariate rows by small GEMMs
@@ -806,7 +817,7 @@ extern "C" int stdadk_forward_f32(const stdadk_basis_desc *b, const stdadk_mlp_d
   STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "forward: X is NULL with p=%d", b->p);
   c.P = P; c.G = nullptr; c.st = (hipStream_t)stream;
   c.dp = training ? d->dropout_p : 0.f; c.seed = drop_seed; c.step_dev = step_dev;
-  return step_forward(c, b, window, coords, t, X, y_pred, stream);
+  return step_forward(c, b, window, coords, t, X, nullptr, y_pred, stream);
 }
 
 extern "C" int stdadk_backward_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
@@ -821,7 +832,7 @@ extern "C" int stdadk_backward_f32(const stdadk_basis_desc *b, const stdadk_mlp_
   if (rc) return rc;
   STDADK_REQUIRE(P && G && dY, STDADK_E_ARG, "backward: NULL pointer");
   c.P = P; c.G = G; c.st = (hipStream_t)stream; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = step_dev;
-  return step_backward(c, b, window, dY);
+  return step_backward(c, b, window, dY, false);
 }
 
 extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
@@ -836,15 +847,22 @@ extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk
   bool window;
   int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
   if (rc) return rc;
-  STDADK_REQUIRE(P && G && coords && t && y && y_pred, STDADK_E_ARG, "train_fwd_bwd: NULL pointer");
+  STDADK_REQUIRE(P && G && coords && t && y, STDADK_E_ARG, "train_fwd_bwd: NULL pointer");
   STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "train_fwd_bwd: X is NULL with p=%d", b->p);
   c.P = P; c.G = G; c.st = (hipStream_t)stream; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = step_dev;
-  rc = step_forward(c, b, window, coords, t, X, y_pred, stream);
+  const int64_t n = B * d->out_dim;
+  if (window) {
+    // everything between the binning and the weight gradients stays in sorted order
+    rc = step_forward(c, b, true, coords, t, X, y, y_pred, stream);
+    if (rc) return rc;
+    rc = launch_mse(c.ws + c.pl.ypred, c.ws + c.pl.y_s, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
+    if (rc) return rc;
+    return step_backward(c, b, true, c.ws + c.pl.dY, true);
+  }
+  float *yp = y_pred ? y_pred : c.ws + c.pl.ypred;
+  rc = step_forward(c, b, false, coords, t, X, nullptr, yp, stream);
   if (rc) return rc;
-  // dY (caller order) lives in the plan's dY buffer for the dense path; the window path gathers it
-  // into that buffer, so stage it in the ypred buffer there (free once y_pred has been un-permuted)
-  float *dY = c.ws + (window ? c.pl.ypred : c.pl.dY);
-  rc = launch_mse(y_pred, y, B * d->out_dim, grad_scale, dY, loss_sum, c.st);
+  rc = launch_mse(yp, y, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
   if (rc) return rc;
-  return step_backward(c, b, window, dY);
+  return step_backward(c, b, false, c.ws + c.pl.dY, false);
 }

@@ -5,8 +5,11 @@
 
 namespace stdadk {
 
+// parts[blockIdx.x] = sum of squares of this block's slice (every one of the SUMSQ_PARTS entries is
+// written, so the buffer needs no zeroing and the sum order is fixed).
+constexpr int SUMSQ_PARTS = STDADK_SUMSQ_PARTS;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ g, int64_t n,
-                                                    float *__restrict__ out) {
+                                                    float *__restrict__ parts) {
   float acc = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -26,7 +29,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ g,
   float s = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0) parts[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 struct AdamArgs {
@@ -34,8 +37,8 @@ struct AdamArgs {
   int64_t n;
   float lr; const float *lr_dev;
   float beta1, beta2, eps, wd;
-  int step; const int *step_dev;
-  float max_norm; const float *sumsq; float grad_mul; float ema_decay;
+  int step; int *step_dev;
+  float max_norm; const float *sumsq; int n_parts; float grad_mul; float ema_decay;
 };
 
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float *ema, float gm,
@@ -54,7 +57,17 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   const float lr = a.lr_dev ? a.lr_dev[0] : a.lr;
   const int step = a.step_dev ? a.step_dev[0] + 1 : a.step;
   float coef = 1.f;
-  if (a.max_norm > 0.f && a.sumsq) coef = fminf(1.f, a.max_norm / (sqrtf(a.sumsq[0]) + 1e-6f));
+  if (a.max_norm > 0.f && a.sumsq) {
+    // block-wide sum of the partials, same order in every block (L2-resident, a few hundred floats)
+    __shared__ float red[4];
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < a.n_parts; i += 256) ss += a.sumsq[i];
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = (red[0] + red[1]) + (red[2] + red[3]);
+    coef = fminf(1.f, a.max_norm / (sqrtf(ss) + 1e-6f));
+  }
   const float gm = coef * a.grad_mul;
   const float bc1 = 1.f - powf(a.beta1, (float)step);
   const float bc2 = 1.f - powf(a.beta2, (float)step);
@@ -94,22 +107,28 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
     a.p[j] = p; a.m[j] = m; a.v[j] = v;
     if (a.ema) a.ema[j] = e;
   }
+  // step_dev[0] += 1 by the LAST block to finish: every block read step_dev[0] before its update
+  // loop, and a block only arrives here after that read (step_dev[1] is the arrival counter).
+  if (a.step_dev) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int done = atomicAdd(&a.step_dev[1], 1);
+      if (done == (int)gridDim.x - 1) {
+        a.step_dev[1] = 0;
+        a.step_dev[0] = step;
+      }
+    }
+  }
 }
-
-__global__ void step_inc_kernel(int *s) { s[0] += 1; }
 
 }  // namespace stdadk
 
 using namespace stdadk;
 
-extern "C" int stdadk_sumsq_f32(const float *g, int64_t n, float *out, stdadk_stream_t stream) {
+extern "C" int stdadk_sumsq_f32(const float *g, int64_t n, float *parts, stdadk_stream_t stream) {
   STDADK_REQUIRE(n >= 0, STDADK_E_ARG, "sumsq: negative n");
-  if (n == 0) return 0;
-  STDADK_REQUIRE(g && out, STDADK_E_ARG, "sumsq: NULL pointer");
-  int64_t blocks = ceil_div(n, 256 * 8);
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  STDADK_REQUIRE(parts && (g || n == 0), STDADK_E_ARG, "sumsq: NULL pointer");
+  STDADK_LAUNCH(sumsq_kernel, dim3(SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, g, n, parts);
   STDADK_CHECK_LAUNCH("sumsq");
   return 0;
 }
@@ -117,24 +136,20 @@ extern "C" int stdadk_sumsq_f32(const float *g, int64_t n, float *out, stdadk_st
 extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
                                     float lr, const float *lr_dev, float beta1, float beta2, float eps,
                                     float weight_decay, int32_t step, int32_t *step_dev, float max_norm,
-                                    const float *sumsq, float grad_mul, float ema_decay,
-                                    stdadk_stream_t stream) {
+                                    const float *sumsq_parts, int32_t n_parts, float grad_mul,
+                                    float ema_decay, stdadk_stream_t stream) {
   STDADK_REQUIRE(n >= 0, STDADK_E_ARG, "adamw: negative n");
   if (n == 0) return 0;
   STDADK_REQUIRE(p && g && m && v, STDADK_E_ARG, "adamw: NULL pointer");
   STDADK_REQUIRE(step_dev || step >= 1, STDADK_E_ARG, "adamw: step must be >= 1");
-  STDADK_REQUIRE(max_norm <= 0.f || sumsq, STDADK_E_ARG, "adamw: max_norm > 0 needs sumsq");
+  STDADK_REQUIRE(max_norm <= 0.f || (sumsq_parts && n_parts > 0), STDADK_E_ARG, "adamw: max_norm > 0 needs sumsq parts");
   AdamArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.ema = ema; a.n = n; a.lr = lr; a.lr_dev = lr_dev;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.step = step; a.step_dev = step_dev;
-  a.max_norm = max_norm; a.sumsq = sumsq; a.grad_mul = grad_mul; a.ema_decay = ema_decay;
+  a.max_norm = max_norm; a.sumsq = sumsq_parts; a.n_parts = n_parts; a.grad_mul = grad_mul; a.ema_decay = ema_decay;
   int64_t blocks = ceil_div(n, 256 * 4);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  STDADK_LAUNCH(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   STDADK_CHECK_LAUNCH("adamw_ema");
-  if (step_dev) {
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
-    STDADK_CHECK_LAUNCH("step_inc");
-  }
   return 0;
 }

@@ -116,11 +116,11 @@ static void launch_rbf(const float *coords, const float *t, const float *X, int6
     if (t1 <= t0) return;
     dim3 grid((unsigned)(t1 - t0), gy);
     if (all_sp)
-      hipLaunchKernelGGL((rbf_build_kernel<VEC, BASIS, true>), grid, dim3(RB_THREADS), 0, st,
+      STDADK_LAUNCH((rbf_build_kernel<VEC, BASIS, true>), grid, dim3(RB_THREADS), 0, st,
                          coords, t, X, B, p, s_centers, s_bw, Ks, cal, t_centers, t_bw, Kt, out,
                          ld_out, rows, t0);
     else
-      hipLaunchKernelGGL((rbf_build_kernel<VEC, BASIS, false>), grid, dim3(RB_THREADS), 0, st,
+      STDADK_LAUNCH((rbf_build_kernel<VEC, BASIS, false>), grid, dim3(RB_THREADS), 0, st,
                          coords, t, X, B, p, s_centers, s_bw, Ks, cal, t_centers, t_bw, Kt, out,
                          ld_out, rows, t0);
   };

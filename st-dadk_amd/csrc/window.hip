@@ -114,12 +114,12 @@ int bin_obs(const float *coords, const float *t, const float *y, int Q, const fl
             int G, const BinBuffers &bb, hipStream_t st) {
   const int ncell = G * G;
   // a kernel, not hipMemsetAsync: the step must stay a pure chain of kernel nodes under capture
-  hipLaunchKernelGGL(zero_ints_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st, bb.hist, ncell);
+  STDADK_LAUNCH(zero_ints_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st, bb.hist, ncell);
   const unsigned nb = (unsigned)ceil_div(B, 256);
-  hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, coords, B, G, bb.keys, bb.hist);
-  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, bb.hist, ncell, bb.cell_start, bb.cursor);
-  hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(256), 0, st, bb.keys, B, bb.cursor, bb.perm_tmp);
-  hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)ceil_div(ncell, 128)), dim3(128), 0, st, bb.cell_start,
+  STDADK_LAUNCH(cell_hist_kernel, dim3(nb), dim3(256), 0, st, coords, B, G, bb.keys, bb.hist);
+  STDADK_LAUNCH(cell_scan_kernel, dim3(1), dim3(1024), 0, st, bb.hist, ncell, bb.cell_start, bb.cursor);
+  STDADK_LAUNCH(cell_scatter_kernel, dim3(nb), dim3(256), 0, st, bb.keys, B, bb.cursor, bb.perm_tmp);
+  STDADK_LAUNCH(cell_order_kernel, dim3((unsigned)ceil_div(ncell, 128)), dim3(128), 0, st, bb.cell_start,
                      ncell, bb.perm_tmp, bb.perm, coords, t, y, Q, X, p, bb.xs, bb.ys, bb.ts,
                      y ? bb.y_s : (float *)nullptr, (X && p > 0) ? bb.X_s : (float *)nullptr);
   STDADK_CHECK_LAUNCH("bin_obs");
@@ -135,7 +135,7 @@ __global__ void unpermute_kernel(const float *__restrict__ in, const int *__rest
 }
 
 int unpermute_rows(const float *in, const int *perm, int B, int Q, float *out, hipStream_t st) {
-  hipLaunchKernelGGL(unpermute_kernel, dim3((unsigned)ceil_div((int64_t)B * Q, 256)), dim3(256), 0, st, in,
+  STDADK_LAUNCH(unpermute_kernel, dim3((unsigned)ceil_div((int64_t)B * Q, 256)), dim3(256), 0, st, in,
                      perm, B, Q, out);
   STDADK_CHECK_LAUNCH("unpermute");
   return 0;
@@ -334,7 +334,7 @@ static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
     if (e != hipSuccess) { set_error("l1_window_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.n_wg), dim3(FW_T), lds, st, a);
+  STDADK_LAUNCH(kern, dim3((unsigned)a.n_wg), dim3(FW_T), lds, st, a);
   STDADK_CHECK_LAUNCH("l1_window_forward");
   return 0;
 }
@@ -363,14 +363,16 @@ constexpr int KBX = 4, KBY = 8, KB = KBX * KBY;   // 32 knots = one MFMA row til
 constexpr int OT = 32;                            // observations per MFMA k-tile
 constexpr int MAX_SEG = 256;                      // cell rows a block may overlap (G <= 256)
 
+constexpr int LCH = 512;                          // observations listed in LDS per pass
+
 template <int TN, int BASIS>
 __global__ __launch_bounds__(256) void l1_window_bwd_kernel(L1BwdArgs a) {
   constexpr int H = 128 * TN;
   __shared__ __attribute__((aligned(16))) float As[OT * KB];      // [obs][knot]
   __shared__ __attribute__((aligned(16))) float Bs[OT * H];       // [obs][col]
   __shared__ int seg_start[MAX_SEG], seg_pref[MAX_SEG + 1];
-  __shared__ int s_idx[OT];
-  __shared__ float s_x[OT], s_y[OT];
+  __shared__ int l_idx[LCH];
+  __shared__ float l_x[LCH], l_y[LCH];
   __shared__ int s_kidx[KB];
   __shared__ float s_box[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -419,7 +421,6 @@ __global__ __launch_bounds__(256) void l1_window_bwd_kernel(L1BwdArgs a) {
   }
   __syncthreads();
   const int total = seg_pref[nseg];
-  const int ntile = (total + OT - 1) / OT;
 
   f32x16 acc[TN];
 #pragma unroll
@@ -427,60 +428,67 @@ __global__ __launch_bounds__(256) void l1_window_bwd_kernel(L1BwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int wn = wave * (H / 4);     // this wave's first output column
+  const int ps = tid >> 3, part = tid & 7;     // dZ staging: 8 threads per observation row
 
-  for (int tile = 0; tile < ntile; ++tile) {
-    if (tid < OT) {
-      const int pos = tile * OT + tid;
-      int idx = -1;
-      if (pos < total) {
-        int s = 0;
-        while (pos >= seg_pref[s + 1]) ++s;
-        idx = seg_start[s] + (pos - seg_pref[s]);
-      }
-      s_idx[tid] = idx;
-      s_x[tid] = idx >= 0 ? a.xs[idx] : 0.f;
-      s_y[tid] = idx >= 0 ? a.ys[idx] : 0.f;
-    }
-    __syncthreads();
-    // phi tile: As[obs][knot]
+  float rphi[OT * KB / 256];
+  float4 rdz[H / 32];
+  // stage tile `tl` of the current list pass (n listed observations) into registers
+  auto load_tile = [&](int tl, int n) {
 #pragma unroll
     for (int j = 0; j < OT * KB / 256; ++j) {
-      const int s = (tid >> 5) + 8 * j;
-      float v = 0.f;
-      if (kvalid && s_idx[s] >= 0) v = phi_eval<BASIS>(s_x[s], s_y[s], kcx, kcy, ksc);
-      As[s * KB + ki] = v;
+      const int q = tl * OT + (tid >> 5) + 8 * j;
+      rphi[j] = (kvalid && q < n) ? phi_eval<BASIS>(l_x[q], l_y[q], kcx, kcy, ksc) : 0.f;
     }
-    // dZ tile: Bs[obs][col], 8 threads per row
-    {
-      const int s = tid >> 3, part = tid & 7;
-      const int idx = s_idx[s];
-      const float4 *src = reinterpret_cast<const float4 *>(a.dZ + (size_t)(idx >= 0 ? idx : 0) * H);
-      float4 *dst = reinterpret_cast<float4 *>(Bs + s * H);
+    const int q = tl * OT + ps;
+    const bool ok = q < n;
+    const float4 *src = reinterpret_cast<const float4 *>(a.dZ + (size_t)(ok ? l_idx[q] : 0) * H);
 #pragma unroll
-      for (int j = 0; j < H / 32; ++j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx >= 0) v = src[part + 8 * j];
-        dst[part + 8 * j] = v;
-      }
+    for (int j = 0; j < H / 32; ++j) rdz[j] = ok ? src[part + 8 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  for (int base = 0; base < total; base += LCH) {
+    const int n = min(LCH, total - base);
+    __syncthreads();                       // previous pass has finished reading the list
+    for (int q = tid; q < n; q += 256) {
+      const int pos = base + q;
+      int s = 0;
+      while (pos >= seg_pref[s + 1]) ++s;
+      const int idx = seg_start[s] + (pos - seg_pref[s]);
+      l_idx[q] = idx;
+      l_x[q] = a.xs[idx];
+      l_y[q] = a.ys[idx];
     }
     __syncthreads();
+    const int nt = (n + OT - 1) / OT;
+    load_tile(0, n);
+    for (int tl = 0; tl < nt; ++tl) {
 #pragma unroll
-    for (int s = 0; s < OT / 8; ++s) {
-      float fa[4], fb[TN][4];
-      const int h = lane >> 5, c = lane & 31;
+      for (int j = 0; j < OT * KB / 256; ++j) As[((tid >> 5) + 8 * j) * KB + ki] = rphi[j];
+      {
+        float4 *dst = reinterpret_cast<float4 *>(Bs + ps * H);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) fa[e] = As[(8 * s + 4 * h + e) * KB + c];
+        for (int j = 0; j < H / 32; ++j) dst[part + 8 * j] = rdz[j];
+      }
+      __syncthreads();
+      if (tl + 1 < nt) load_tile(tl + 1, n);      // global loads in flight under the MFMAs below
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int s = 0; s < OT / 8; ++s) {
+        float fa[4], fb[TN][4];
+        const int h = lane >> 5, c = lane & 31;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) fb[j][e] = Bs[(8 * s + 4 * h + e) * H + wn + j * 32 + c];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e) fa[e] = As[(8 * s + 4 * h + e) * KB + c];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fb[j][e] = Bs[(8 * s + 4 * h + e) * H + wn + j * 32 + c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc[j], 0, 0, 0);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // every valid knot row of the block is written (zeros when no observation is in reach)
@@ -505,7 +513,7 @@ int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st) {
   }
   a.blk_off[a.g.n_levels] = nblk;
   STDADK_REQUIRE(a.G <= MAX_SEG, STDADK_E_ARG, "l1_window_backward: G too large");
-#define GO(TN_, BS_) hipLaunchKernelGGL((l1_window_bwd_kernel<TN_, BS_>), dim3((unsigned)nblk), dim3(256), 0, st, a)
+#define GO(TN_, BS_) STDADK_LAUNCH((l1_window_bwd_kernel<TN_, BS_>), dim3((unsigned)nblk), dim3(256), 0, st, a)
   if (a.H == 256) { if (basis == STDADK_BASIS_WENDLAND) GO(2, 0); else GO(2, 2); }
   else if (a.H == 128) { if (basis == STDADK_BASIS_WENDLAND) GO(1, 0); else GO(1, 2); }
   else { set_error("l1_window_backward: H=%d unsupported", a.H); return STDADK_E_SHAPE; }
@@ -550,7 +558,7 @@ extern "C" int stdadk_knot_windows_i32(const float *coords, int64_t B, const int
     lt.off[l] = off;
     off += sides_host[l] * sides_host[l];
   }
-  hipLaunchKernelGGL(knot_windows_kernel, dim3((unsigned)ceil_div(B * n_levels, 256)), dim3(256), 0,
+  STDADK_LAUNCH(knot_windows_kernel, dim3((unsigned)ceil_div(B * n_levels, 256)), dim3(256), 0,
                      (hipStream_t)stream, coords, (int)B, (int)n_levels, lt, p, ix0, iy0, col0);
   STDADK_CHECK_LAUNCH("knot_windows");
   return 0;

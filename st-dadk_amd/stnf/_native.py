@@ -80,6 +80,8 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "stdadk_knot_windows_i32": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int32,
                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stdadk_profile_enable": (C.c_int, [C.c_int32]),
+    "stdadk_profile_collect": (C.c_int64, [C.c_char_p, C.c_int64]),
     "stdadk_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "stdadk_gemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
@@ -88,7 +90,7 @@ _SIGNATURES = {
     "stdadk_adamw_ema_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_float, C.c_void_p, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float,
-                                       C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+                                       C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
 }
 
 
@@ -323,16 +325,44 @@ def mse(y_pred, y, grad_scale, dY=None, loss_sum=None):
     _check(rc, "stdadk_mse_f32")
 
 
-def sumsq(g, out):
-    rc = lib().stdadk_sumsq_f32(_dev(g, "g"), g.numel(), _dev(out, "out"), _stream())
+SUMSQ_PARTS = 256
+
+
+def sumsq(g, parts):
+    """parts[0:256] = partial sums of g^2 (`parts` is a 256-float slice, fully overwritten)."""
+    if parts.numel() != SUMSQ_PARTS:
+        raise RuntimeError(f"sumsq: parts must hold {SUMSQ_PARTS} floats")
+    rc = lib().stdadk_sumsq_f32(_dev(g, "g"), g.numel(), _dev(parts, "parts"), _stream())
     _check(rc, "stdadk_sumsq_f32")
 
 
-def adamw_ema(p, g, m, v, ema, lr, betas, eps, weight_decay, step, max_norm=0.0, sumsq_buf=None,
+def adamw_ema(p, g, m, v, ema, lr, betas, eps, weight_decay, step, max_norm=0.0, sumsq_parts=None,
               grad_mul=1.0, ema_decay=0.0, lr_dev=None, step_dev=None):
+    if step_dev is not None and step_dev.numel() < 2:
+        raise RuntimeError("adamw_ema: step_dev must be an int32 tensor of 2 elements")
     rc = lib().stdadk_adamw_ema_f32(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"),
                                     _dev(ema, "ema"), p.numel(), lr, _dev(lr_dev, "lr_dev"),
                                     betas[0], betas[1], eps, weight_decay, int(step),
-                                    _dev(step_dev, "step_dev"), max_norm, _dev(sumsq_buf, "sumsq"),
+                                    _dev(step_dev, "step_dev"), max_norm, _dev(sumsq_parts, "sumsq"),
+                                    0 if sumsq_parts is None else sumsq_parts.numel(),
                                     grad_mul, ema_decay, _stream())
     _check(rc, "stdadk_adamw_ema_f32")
+
+
+def profile_enable(on=True):
+    """Bracket every kernel launch of the library with HIP events (measurement aid)."""
+    lib().stdadk_profile_enable(int(on))
+
+
+def profile_collect():
+    """[(kernel name, milliseconds)] per launch since profile_enable(True), in launch order."""
+    need = lib().stdadk_profile_collect(None, 0)
+    if need < 0:
+        raise RuntimeError("stdadk_profile_collect failed")
+    buf = C.create_string_buffer(int(need) + 16)
+    lib().stdadk_profile_collect(buf, len(buf))
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, ms = line.rsplit("\t", 1)
+        out.append((name, float(ms)))
+    return out

@@ -87,9 +87,9 @@ class TrainStep:
                               device=self.dev)
         self.y_pred = torch.empty(B, model.output_dim, device=self.dev)
         self.loss_sum = torch.zeros(1, device=self.dev)       # running sum of squared errors
-        self.sumsq = torch.zeros(1, device=self.dev)
+        self.sumsq = torch.zeros(N.SUMSQ_PARTS, device=self.dev)
         self.lr_dev = torch.full((1,), self.lr, device=self.dev)
-        self.step_dev = torch.zeros(1, device=self.dev, dtype=torch.int32)
+        self.step_dev = torch.zeros(2, device=self.dev, dtype=torch.int32)
         self.seed = 0x5DEECE66D
         self.rows_seen = 0
         # distributed
@@ -116,15 +116,14 @@ class TrainStep:
         Q = self.model.output_dim
         # d(mean over the GLOBAL batch)/dparams: each rank scales by 1/global_rows, the all-reduce SUMs
         N.train_fwd_bwd(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, B,
-                        1.0 / (global_rows * Q), self.loss_sum, self.y_pred, self.ws, st.flags,
+                        1.0 / (global_rows * Q), self.loss_sum, None, self.ws, st.flags,
                         seed=self.seed, step_dev=self.step_dev)
         if self.distributed:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
         if self.grad_clip > 0:
-            self.sumsq.zero_()
             N.sumsq(self.grad, self.sumsq)
         N.adamw_ema(self.flat, self.grad, self.m, self.v, self.ema, self.lr, self.betas, self.eps,
-                    self.wd, self.step_count + 1, max_norm=self.grad_clip, sumsq_buf=self.sumsq,
+                    self.wd, self.step_count + 1, max_norm=self.grad_clip, sumsq_parts=self.sumsq,
                     ema_decay=self.ema_decay, lr_dev=self.lr_dev, step_dev=self.step_dev)
 
     def step(self, X, coords, t, y, global_rows=None):

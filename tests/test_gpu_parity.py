@@ -299,12 +299,13 @@ def test_optimizer_steps_match_reference(name):
         loss = torch.nn.MSELoss()(m(X, coords, t), y)
         loss.backward()
         losses.append(loss.item())
-        ss = torch.zeros(1, device=d)
-        for _, p in plist:
-            N.sumsq(p.grad, ss)
+        ss = torch.empty(len(plist) * N.SUMSQ_PARTS, device=d)
+        for i, (_, p) in enumerate(plist):
+            N.sumsq(p.grad.contiguous(), ss[i * N.SUMSQ_PARTS:(i + 1) * N.SUMSQ_PARTS])
         for (_, p), mm, vv, ee in zip(plist, ms, vs, ema):
-            N.adamw_ema(p.data, p.grad, mm, vv, ee, o["lr"], o["betas"], o["eps"], o["weight_decay"],
-                        step, max_norm=o["grad_clip"], sumsq_buf=ss, ema_decay=o["ema_decay"])
+            N.adamw_ema(p.data, p.grad.contiguous(), mm, vv, ee, o["lr"], o["betas"], o["eps"],
+                        o["weight_decay"], step, max_norm=o["grad_clip"], sumsq_parts=ss,
+                        ema_decay=o["ema_decay"])
     assert np.abs(np.array(losses) - g["opt_losses64"]).max() <= 5 * TOL * max(1.0, g["opt_losses64"].max())
     for (k, p), ee in zip(plist, ema):
         check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=2e-5)
