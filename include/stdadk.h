@@ -128,15 +128,20 @@ int stdadk_mse_f32(const float *y_pred, const float *y, int64_t n, float grad_sc
  *       p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps);
  *       ema = decay*ema + (1-decay)*p   (skipped when ema == NULL)
  *   lr is read from the device scalar lr_dev[0] when non-NULL (graph-replayable schedules),
- *   else from `lr`.  `step` is the 1-based step count (host value); when step_dev (device
- *   int32[2], both zero-initialised: [0] completed steps, [1] scratch) is non-NULL the kernel uses
- *   step_dev[0]+1 and stores it back when the update has finished.
+ *   else from `lr`.  The 1-based number of the step being applied is `step` (host value) or, when
+ *   step_dev is non-NULL, the device scalar step_dev[0].  That counter also feeds the dropout
+ *   generator (as "steps completed") in the forward/backward of a step, so it must be advanced
+ *   AFTER the backward and BEFORE stdadk_adamw_ema_f32: pass it as `step_inc` to
+ *   stdadk_sumsq_f32 (block 0 adds 1) or call stdadk_step_advance when no clipping is used.
  * ------------------------------------------------------------------------------------------ */
-int stdadk_sumsq_f32(const float *g, int64_t n, float *parts, stdadk_stream_t stream);
+int stdadk_sumsq_f32(const float *g, int64_t n, float *parts, int32_t *step_inc,
+                     stdadk_stream_t stream);
+
+int stdadk_step_advance(int32_t *step_dev, stdadk_stream_t stream);
 
 int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
                          float lr, const float *lr_dev, float beta1, float beta2, float eps,
-                         float weight_decay, int32_t step, int32_t *step_dev, float max_norm,
+                         float weight_decay, int32_t step, const int32_t *step_dev, float max_norm,
                          const float *sumsq_parts, int32_t n_parts, float grad_mul, float ema_decay,
                          stdadk_stream_t stream);
 
@@ -150,7 +155,7 @@ int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *em
  *            grid of _init_uniform (st_interp.py:152-185) only the <= 6x6 knots per level that can
  *            be non-zero for an observation are touched: observations are binned into a G x G
  *            cell grid, layer 0 gathers W0^T rows per observation (fused with LayerNorm/ReLU/
- *            Dropout) and dW0^T is accumulated by one workgroup per 4x8 knot block.  phi is
+ *            Dropout) and every row of dW0^T is accumulated by the one wave that owns it.  phi is
  *            evaluated with the same arithmetic as the dense path; exact zeros are skipped.
  * The window path needs the first layer's weight (and gradient) stored TRANSPOSED, (in,out)
  * row-major (flag STDADK_FLAG_W0_T), hidden[0] in {128, 256} and p <= 16; otherwise, or with

@@ -11,6 +11,9 @@
 #include "common.h"
 #include "gemm_f32.h"
 #include "window.h"
+#include "tail.h"
+
+#include <stdlib.h>
 
 namespace stdadk {
 
@@ -35,6 +38,7 @@ struct Plan {
   size_t slab, slab_floats;
   size_t dA, dZ;            // [B][hmax] each
   size_t part, part_floats; // column-sum partials
+  size_t dZl[STDADK_MAX_HIDDEN], partl[STDADK_MAX_HIDDEN];   // fused tail: per-layer dZ and partials
   // step-level buffers
   size_t feats; int64_t ldf;           // dense: materialised features
   size_t psi; int ld_psi;              // window: temporal basis [B][ld_psi]
@@ -89,7 +93,16 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
   p->part_floats = (size_t)nblk * 3 * hmax;
   size_t head = (size_t)nblk * (size_t)d->out_dim * (hmax + 1);
   if (head > p->part_floats) p->part_floats = head;
+  {
+    const int64_t nb16 = ceil_div(B, TAIL_ROWS);
+    size_t head16 = (size_t)nb16 * (size_t)d->out_dim * (hmax + 1);
+    if (head16 > p->part_floats) p->part_floats = head16;
+  }
   p->part = take(p->part_floats);
+  for (int l = 0; l < d->n_hidden; ++l) {
+    p->dZl[l] = take((size_t)B * d->hidden[l]);
+    p->partl[l] = take((size_t)ceil_div(B, TAIL_ROWS) * 3 * d->hidden[l]);
+  }
   p->feats = p->psi = p->ypred = p->dY = 0;
   p->ldf = 0; p->ld_psi = 0; p->G = 0;
   if (mode != PLAN_MLP) {
@@ -433,9 +446,74 @@ struct Ctx {
   uint64_t seed;
   const int *step_dev;
   const uint8_t *const *masks;
+  // fused MSE (tail path): targets in the row order of the activations; outputs optional
+  const float *mse_y = nullptr;
+  float mse_scale = 0.f;
+  float *mse_dY = nullptr;
+  float *mse_loss = nullptr;
+  bool mse_done = false;        // set by run_forward when the loss was fused into the tail kernel
+  const float *dz0 = nullptr;   // set by run_backward: dZ of layer 0
 };
 
-// hidden layers [l0, L) and the output layer; `in` = input of layer l0
+static bool tail_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("STDADK_NO_FUSED_TAIL");
+    v = (e && e[0] == '1') ? 0 : 1;
+  }
+  return v != 0;
+}
+
+static TailLayer tail_layer(const Ctx &c, int l) {
+  TailLayer t;
+  const stdadk_mlp_desc *d = c.d;
+  t.W = c.P->W[l]; t.b = c.P->b[l];
+  t.g = d->layernorm ? c.P->ln_g[l] : nullptr;
+  t.be = d->layernorm ? c.P->ln_b[l] : nullptr;
+  t.h = d->hidden[l];
+  t.hp = l > 0 ? d->hidden[l - 1] : d->in_dim;
+  t.xhat = c.ws + c.pl.xhat[l]; t.rstd = c.ws + c.pl.rstd[l]; t.act = c.ws + c.pl.act[l];
+  t.layer_id = l;
+  return t;
+}
+
+// one hidden layer with the generic kernels: z = in W^T (+b) -> LN -> ReLU -> Dropout
+static int generic_layer_forward(Ctx &c, int l, const float *in, int64_t ld_in, int K) {
+  const stdadk_mlp_desc *d = c.d;
+  const stdadk_mlp_tensors *P = c.P;
+  float *ws = c.ws;
+  const Plan &pl = c.pl;
+  const int64_t B = c.B;
+  hipStream_t st = c.st;
+  const int h = d->hidden[l];
+  STDADK_REQUIRE(P->W[l] && P->b[l], STDADK_E_ARG, "mlp_forward: layer %d weights NULL", l);
+  STDADK_REQUIRE(!d->layernorm || (P->ln_g[l] && P->ln_b[l]), STDADK_E_ARG, "mlp_forward: layer %d LN NULL", l);
+  float *xh = ws + pl.xhat[l], *act = ws + pl.act[l];
+  int splits = 1, rc;
+  // z partials: slabs when split, else straight into the xhat buffer (normalised in place below)
+  if (l == 0 && c.w0t)
+    rc = gemm_run(in, ld_in, false, P->W[l], h, true, (int)B, h, K, nullptr, xh, h, ws + pl.slab, true, &splits, st);
+  else
+    rc = gemm_run(in, ld_in, false, P->W[l], K, false, (int)B, h, K, nullptr, xh, h, ws + pl.slab, true, &splits, st);
+  if (rc) return rc;
+  const float *zsrc = splits > 1 ? ws + pl.slab : xh;
+  const uint8_t *mk = (c.masks && c.dp > 0.f) ? c.masks[l] : nullptr;
+  dim3 grid((unsigned)ceil_div(B, ROW_T / 64));
+#define FWD(LN_, CPL_)                                                                                   \
+  STDADK_LAUNCH((ln_relu_fwd_kernel<LN_, CPL_>), grid, dim3(ROW_T), 0, st, zsrc, splits,                 \
+                (int64_t)B * h, P->b[l], LN_ ? P->ln_g[l] : (const float *)nullptr,                      \
+                LN_ ? P->ln_b[l] : (const float *)nullptr, d->ln_eps, B, h, xh, ws + pl.rstd[l],         \
+                act, c.dp, c.seed, c.step_dev, l, mk)
+  if (d->layernorm) { if (h <= 64) FWD(true, 1); else if (h <= 128) FWD(true, 2); else if (h <= 256) FWD(true, 4); else FWD(true, 16); }
+  else { if (h <= 64) FWD(false, 1); else if (h <= 128) FWD(false, 2); else if (h <= 256) FWD(false, 4); else FWD(false, 16); }
+#undef FWD
+  STDADK_CHECK_LAUNCH("ln_relu_fwd");
+  return 0;
+}
+
+// hidden layers [l0, L) and the output layer; `in` = input of layer l0.  When the fused tail
+// applies, every layer after the first, the output layer and (if c.mse_y is set) the MSE loss run
+// in ONE kernel.
 static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, float *y_pred) {
   const stdadk_mlp_desc *d = c.d;
   const stdadk_mlp_tensors *P = c.P;
@@ -443,38 +521,42 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
   const Plan &pl = c.pl;
   const int64_t B = c.B;
   hipStream_t st = c.st;
-  int rc;
-  for (int l = l0; l < d->n_hidden; ++l) {
-    const int h = d->hidden[l];
-    STDADK_REQUIRE(P->W[l] && P->b[l], STDADK_E_ARG, "mlp_forward: layer %d weights NULL", l);
-    STDADK_REQUIRE(!d->layernorm || (P->ln_g[l] && P->ln_b[l]), STDADK_E_ARG, "mlp_forward: layer %d LN NULL", l);
-    float *xh = ws + pl.xhat[l], *act = ws + pl.act[l];
-    int splits = 1;
-    // z partials: slabs when split, else straight into the xhat buffer (normalised in place below)
-    if (l == 0 && c.w0t)
-      rc = gemm_run(in, ld_in, false, P->W[l], h, true, (int)B, h, K, nullptr, xh, h, ws + pl.slab, true, &splits, st);
-    else
-      rc = gemm_run(in, ld_in, false, P->W[l], K, false, (int)B, h, K, nullptr, xh, h, ws + pl.slab, true, &splits, st);
-    if (rc) return rc;
-    const float *zsrc = splits > 1 ? ws + pl.slab : xh;
-    const uint8_t *mk = (c.masks && c.dp > 0.f) ? c.masks[l] : nullptr;
-    dim3 grid((unsigned)ceil_div(B, ROW_T / 64));
-#define FWD(LN_, CPL_)                                                                                   \
-  STDADK_LAUNCH((ln_relu_fwd_kernel<LN_, CPL_>), grid, dim3(ROW_T), 0, st, zsrc, splits,            \
-                     (int64_t)B * h, P->b[l], LN_ ? P->ln_g[l] : (const float *)nullptr,                 \
-                     LN_ ? P->ln_b[l] : (const float *)nullptr, d->ln_eps, B, h, xh, ws + pl.rstd[l],    \
-                     act, c.dp, c.seed, c.step_dev, l, mk)
-    if (d->layernorm) { if (h <= 64) FWD(true, 1); else if (h <= 128) FWD(true, 2); else if (h <= 256) FWD(true, 4); else FWD(true, 16); }
-    else { if (h <= 64) FWD(false, 1); else if (h <= 128) FWD(false, 2); else if (h <= 256) FWD(false, 4); else FWD(false, 16); }
-#undef FWD
-    STDADK_CHECK_LAUNCH("ln_relu_fwd");
-    in = act; ld_in = h; K = h;
-  }
   const int L = d->n_hidden, Q = d->out_dim;
+  int rc;
+  c.mse_done = false;
   STDADK_REQUIRE(P->W[L] && P->b[L], STDADK_E_ARG, "mlp_forward: output layer weights NULL");
+  if (tail_enabled() && !c.masks && L >= 1 && tail_supported(d, 1)) {
+    int l = l0;
+    if (l == 0) {
+      rc = generic_layer_forward(c, 0, in, ld_in, K);
+      if (rc) return rc;
+      l = 1;
+    }
+    TailFwdArgs a;
+    a.n_layers = L - l;
+    for (int i = l; i < L; ++i) {
+      STDADK_REQUIRE(P->W[i] && P->b[i] && (!d->layernorm || (P->ln_g[i] && P->ln_b[i])), STDADK_E_ARG,
+                     "mlp_forward: layer %d parameters NULL", i);
+      a.L[i - l] = tail_layer(c, i);
+    }
+    a.a_in = ws + pl.act[l - 1];
+    a.h_in = d->hidden[l - 1];
+    a.B = (int)B;
+    a.Wo = P->W[L]; a.bo = P->b[L]; a.Q = Q;
+    a.y_pred = y_pred;
+    a.y = c.mse_y; a.grad_scale = c.mse_scale; a.dY = c.mse_dY; a.loss_sum = c.mse_loss;
+    a.layernorm = d->layernorm; a.eps = d->ln_eps; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
+    c.mse_done = c.mse_y != nullptr;
+    return tail_forward(a, st);
+  }
+  for (int l = l0; l < L; ++l) {
+    rc = generic_layer_forward(c, l, in, ld_in, K);
+    if (rc) return rc;
+    in = ws + pl.act[l]; ld_in = d->hidden[l]; K = d->hidden[l];
+  }
   if (Q <= HEAD_MAXQ && ld_in == K) {
     STDADK_LAUNCH(head_fwd_kernel, dim3((unsigned)ceil_div(B, ROW_T / 64)), dim3(ROW_T), 0, st, in, B,
-                       K, P->W[L], P->b[L], Q, y_pred);
+                  K, P->W[L], P->b[L], Q, y_pred);
     STDADK_CHECK_LAUNCH("head_fwd");
   } else {
     STDADK_REQUIRE(!(L == 0 && c.w0t), STDADK_E_ARG, "mlp_forward: transposed W0 needs a hidden layer");
@@ -498,6 +580,60 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
   const int64_t nblk = ceil_div(B, rows);
   float *dA = ws + pl.dA, *dZ = ws + pl.dZ, *part = ws + pl.part, *slab = ws + pl.slab;
   int rc;
+  c.dz0 = dZ;
+
+  if (tail_enabled() && !c.masks && L >= 1 && tail_supported(d, 1)) {
+    // one kernel for the whole activation-gradient path, then reductions and the dW GEMMs
+    const int64_t nb16 = ceil_div(B, TAIL_ROWS);
+    const int hL = d->hidden[L - 1];
+    TailBwdArgs a;
+    a.n_layers = L;
+    for (int l = 0; l < L; ++l) {
+      STDADK_REQUIRE(G->W[l] && G->b[l] && (!d->layernorm || (G->ln_g[l] && G->ln_b[l])), STDADK_E_ARG,
+                     "mlp_backward: layer %d grads NULL", l);
+      a.L[l] = tail_layer(c, l);
+      a.dZ[l] = ws + pl.dZl[l];
+      a.part[l] = ws + pl.partl[l];
+    }
+    STDADK_REQUIRE(G->W[L] && G->b[L], STDADK_E_ARG, "mlp_backward: output layer grads NULL");
+    a.B = (int)B; a.Wo = P->W[L]; a.Q = Q; a.dY = dY;
+    a.act_last = ws + pl.act[L - 1]; a.part_head = part;
+    a.layernorm = d->layernorm; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
+    rc = tail_backward(a, st);
+    if (rc) return rc;
+    c.dz0 = ws + pl.dZl[0];
+    {
+      int n = Q * (hL + 1);
+      STDADK_LAUNCH(head_reduce_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64 * CS_G), 0, st, part, nb16, Q, hL,
+                    G->W[L], G->b[L]);
+      STDADK_CHECK_LAUNCH("head_reduce");
+    }
+    for (int l = L - 1; l >= 0; --l) {
+      const int h = d->hidden[l];
+      ColsumOut co;
+      if (d->layernorm) {
+        co.o[0] = G->ln_g[l]; co.o[1] = G->ln_b[l]; co.o[2] = G->b[l];
+        STDADK_LAUNCH(colsum_kernel, dim3((unsigned)ceil_div(3 * h, 64)), dim3(64 * CS_G), 0, st, ws + pl.partl[l],
+                      nb16, (int64_t)3 * h, h, 3, co);
+      } else {
+        co.o[0] = G->b[l]; co.o[1] = co.o[2] = nullptr;
+        STDADK_LAUNCH(colsum_kernel, dim3((unsigned)ceil_div(h, 64)), dim3(64 * CS_G), 0, st,
+                      ws + pl.partl[l] + 2 * h, nb16, (int64_t)3 * h, h, 1, co);
+      }
+      STDADK_CHECK_LAUNCH("colsum");
+      if (l == 0 && !layer0_dense) break;
+      const float *ain = l > 0 ? ws + pl.act[l - 1] : features;
+      const int64_t ldin = l > 0 ? d->hidden[l - 1] : ldf;
+      const int kin = l > 0 ? d->hidden[l - 1] : d->in_dim;
+      const float *dZl = ws + pl.dZl[l];
+      if (l == 0 && c.w0t)
+        rc = gemm_run(ain, ldin, true, dZl, h, true, kin, h, (int)B, nullptr, G->W[l], h, slab, false, nullptr, st);
+      else
+        rc = gemm_run(dZl, h, true, ain, ldin, true, h, kin, (int)B, nullptr, G->W[l], kin, slab, false, nullptr, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
 
   const float *aL = L > 0 ? ws + pl.act[L - 1] : features;
   const int64_t ldaL = L > 0 ? d->hidden[L - 1] : ldf;
@@ -789,14 +925,14 @@ static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const 
   a.xs = ws + c.pl.xs; a.ys = ws + c.pl.ys;
   a.cell_start = (const int *)(ws + c.pl.cell_start);
   a.G = c.pl.G; a.B = (int)c.B; a.H = H;
-  a.dZ = ws + c.pl.dZ; a.dW0T = c.G->W[0];
+  a.dZ = c.dz0; a.dW0T = c.G->W[0];
   rc = l1_window_backward(a, b->basis, c.st);
   if (rc) return rc;
-  rc = gemm_run(ws + c.pl.psi, c.pl.ld_psi, true, ws + c.pl.dZ, H, true, (int)b->Kt, H, (int)c.B, nullptr,
+  rc = gemm_run(ws + c.pl.psi, c.pl.ld_psi, true, c.dz0, H, true, (int)b->Kt, H, (int)c.B, nullptr,
                 c.G->W[0] + (size_t)(b->p + b->Ks) * H, H, ws + c.pl.slab, false, nullptr, c.st);
   if (rc) return rc;
   if (b->p > 0) {
-    rc = gemm_run(ws + c.pl.X_s, b->p, true, ws + c.pl.dZ, H, true, b->p, H, (int)c.B, nullptr, c.G->W[0], H,
+    rc = gemm_run(ws + c.pl.X_s, b->p, true, c.dz0, H, true, b->p, H, (int)c.B, nullptr, c.G->W[0], H,
                   ws + c.pl.slab, false, nullptr, c.st);
     if (rc) return rc;
   }
@@ -851,18 +987,25 @@ extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk
   STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "train_fwd_bwd: X is NULL with p=%d", b->p);
   c.P = P; c.G = G; c.st = (hipStream_t)stream; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = step_dev;
   const int64_t n = B * d->out_dim;
+  c.mse_scale = grad_scale; c.mse_dY = c.ws + c.pl.dY; c.mse_loss = loss_sum;
   if (window) {
     // everything between the binning and the weight gradients stays in sorted order
+    c.mse_y = c.ws + c.pl.y_s;
     rc = step_forward(c, b, true, coords, t, X, y, y_pred, stream);
     if (rc) return rc;
-    rc = launch_mse(c.ws + c.pl.ypred, c.ws + c.pl.y_s, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
-    if (rc) return rc;
+    if (!c.mse_done) {
+      rc = launch_mse(c.ws + c.pl.ypred, c.ws + c.pl.y_s, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
+      if (rc) return rc;
+    }
     return step_backward(c, b, true, c.ws + c.pl.dY, true);
   }
   float *yp = y_pred ? y_pred : c.ws + c.pl.ypred;
+  c.mse_y = y;
   rc = step_forward(c, b, false, coords, t, X, nullptr, yp, stream);
   if (rc) return rc;
-  rc = launch_mse(yp, y, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
-  if (rc) return rc;
+  if (!c.mse_done) {
+    rc = launch_mse(yp, y, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
+    if (rc) return rc;
+  }
   return step_backward(c, b, false, c.ws + c.pl.dY, false);
 }

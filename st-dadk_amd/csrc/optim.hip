@@ -9,7 +9,8 @@ namespace stdadk {
 // written, so the buffer needs no zeroing and the sum order is fixed).
 constexpr int SUMSQ_PARTS = STDADK_SUMSQ_PARTS;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ g, int64_t n,
-                                                    float *__restrict__ parts) {
+                                                    float *__restrict__ parts, int *__restrict__ step_inc) {
+  if (step_inc && blockIdx.x == 0 && threadIdx.x == 0) step_inc[0] += 1;   // nobody else touches it here
   float acc = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,7 +38,7 @@ struct AdamArgs {
   int64_t n;
   float lr; const float *lr_dev;
   float beta1, beta2, eps, wd;
-  int step; int *step_dev;
+  int step; const int *step_dev;
   float max_norm; const float *sumsq; int n_parts; float grad_mul; float ema_decay;
 };
 
@@ -55,7 +56,7 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   const float lr = a.lr_dev ? a.lr_dev[0] : a.lr;
-  const int step = a.step_dev ? a.step_dev[0] + 1 : a.step;
+  const int step = a.step_dev ? a.step_dev[0] : a.step;
   float coef = 1.f;
   if (a.max_norm > 0.f && a.sumsq) {
     // block-wide sum of the partials, same order in every block (L2-resident, a few hundred floats)
@@ -107,35 +108,33 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
     a.p[j] = p; a.m[j] = m; a.v[j] = v;
     if (a.ema) a.ema[j] = e;
   }
-  // step_dev[0] += 1 by the LAST block to finish: every block read step_dev[0] before its update
-  // loop, and a block only arrives here after that read (step_dev[1] is the arrival counter).
-  if (a.step_dev) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int done = atomicAdd(&a.step_dev[1], 1);
-      if (done == (int)gridDim.x - 1) {
-        a.step_dev[1] = 0;
-        a.step_dev[0] = step;
-      }
-    }
-  }
 }
+
+__global__ void step_advance_kernel(int *s) { s[0] += 1; }
 
 }  // namespace stdadk
 
 using namespace stdadk;
 
-extern "C" int stdadk_sumsq_f32(const float *g, int64_t n, float *parts, stdadk_stream_t stream) {
+extern "C" int stdadk_step_advance(int32_t *step_dev, stdadk_stream_t stream) {
+  STDADK_REQUIRE(step_dev, STDADK_E_ARG, "step_advance: NULL pointer");
+  STDADK_LAUNCH(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  STDADK_CHECK_LAUNCH("step_advance");
+  return 0;
+}
+
+extern "C" int stdadk_sumsq_f32(const float *g, int64_t n, float *parts, int32_t *step_inc,
+                                stdadk_stream_t stream) {
   STDADK_REQUIRE(n >= 0, STDADK_E_ARG, "sumsq: negative n");
   STDADK_REQUIRE(parts && (g || n == 0), STDADK_E_ARG, "sumsq: NULL pointer");
-  STDADK_LAUNCH(sumsq_kernel, dim3(SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, g, n, parts);
+  STDADK_LAUNCH(sumsq_kernel, dim3(SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, g, n, parts, step_inc);
   STDADK_CHECK_LAUNCH("sumsq");
   return 0;
 }
 
 extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
                                     float lr, const float *lr_dev, float beta1, float beta2, float eps,
-                                    float weight_decay, int32_t step, int32_t *step_dev, float max_norm,
+                                    float weight_decay, int32_t step, const int32_t *step_dev, float max_norm,
                                     const float *sumsq_parts, int32_t n_parts, float grad_mul,
                                     float ema_decay, stdadk_stream_t stream) {
   STDADK_REQUIRE(n >= 0, STDADK_E_ARG, "adamw: negative n");

@@ -1,0 +1,67 @@
+// Fused "tail" of the MLP: every hidden layer after the first, the output layer and the MSE loss in
+// ONE forward kernel, and the whole data path of backward (dA / dZ of every layer) in ONE kernel.
+// All of it is row-local, so a workgroup carries a 16-row tile through the layers with the
+// activations in LDS and the weights streamed from L2 in 32-deep K chunks onto the matrix cores.
+#pragma once
+#include "common.h"
+
+namespace stdadk {
+
+constexpr int TAIL_MAX_LAYERS = STDADK_MAX_HIDDEN;   // hidden layers handled by one launch
+constexpr int TAIL_ROWS = 16;                        // rows per workgroup (one 16x16x4 MFMA row tile)
+constexpr int TAIL_MAX_W = 256;                      // widest layer the LDS plan holds
+constexpr int TAIL_MAXQ = 8;
+
+struct TailLayer {
+  const float *W;      // [h][hp]  (nn.Linear layout)
+  const float *b;      // [h]
+  const float *g;      // LayerNorm gamma / beta or NULL
+  const float *be;
+  int h, hp;           // out / in width
+  float *xhat;         // [B][h] saved normalised pre-activation (z when no LayerNorm)
+  float *rstd;         // [B]
+  float *act;          // [B][h] post ReLU/Dropout
+  int layer_id;        // index in the model (dropout stream id)
+};
+
+struct TailFwdArgs {
+  int n_layers;                 // tail hidden layers in this launch (may be 0: head only)
+  TailLayer L[TAIL_MAX_LAYERS];
+  const float *a_in;            // [B][h_in] input activations of the first tail layer
+  int h_in;
+  int B;
+  const float *Wo, *bo;         // output layer [Q][h_last], [Q]
+  int Q;
+  float *y_pred;                // [B][Q]
+  const float *y;               // targets in the same row order, or NULL (no loss)
+  float grad_scale;
+  float *dY;                    // [B][Q] = 2 (y_pred - y) grad_scale, or NULL
+  float *loss_sum;              // += sum (y_pred - y)^2, or NULL
+  int layernorm;
+  float eps, drop_p;
+  uint64_t seed;
+  const int *step_dev;
+};
+
+struct TailBwdArgs {
+  int n_layers;                 // hidden layers in this launch: model layers first_layer .. first_layer+n-1
+  TailLayer L[TAIL_MAX_LAYERS]; // L[0] is the FIRST of them (its W is not needed: no dA below it)
+  int B;
+  const float *Wo;              // [Q][h_last]
+  int Q;
+  const float *dY;              // [B][Q]
+  const float *act_last;        // [B][h_last] activations feeding the output layer
+  float *part_head;             // [nblk][Q][h_last+1] partials of dWo (last column: dbo)
+  float *dZ[TAIL_MAX_LAYERS];   // [B][h_l] out: gradient w.r.t. the pre-LayerNorm output of layer l
+  float *part[TAIL_MAX_LAYERS]; // [nblk][3][h_l] column partials (dgamma, dbeta, db) per workgroup
+  int layernorm;
+  float drop_p;
+  uint64_t seed;
+  const int *step_dev;
+};
+
+bool tail_supported(const stdadk_mlp_desc *d, int first_layer);
+int tail_forward(const TailFwdArgs &a, hipStream_t st);
+int tail_backward(const TailBwdArgs &a, hipStream_t st);
+
+}  // namespace stdadk

@@ -67,12 +67,10 @@ struct L1BwdArgs {
   int G, B, H;
   const float *dZ;      // [B][H] sorted order
   float *dW0T;          // [D][H]
-  int blk_off[STDADK_MAX_LEVELS + 1];  // first block of every level
-  int nbx[STDADK_MAX_LEVELS], nby[STDADK_MAX_LEVELS];
 };
 
-// dW0T[p + k, :] = sum_b phi[b,k] dZ[b,:] for every spatial knot k (each knot block owned by one
-// workgroup: no atomics, summation in sorted-observation order => bitwise reproducible).
+// dW0T[p + k, :] = sum_b phi[b,k] dZ[b,:] for every spatial knot k (each knot row owned by one
+// wave: no atomics, summation in sorted-observation order => bitwise reproducible).
 int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st);
 
 // out[perm[i]*Q + q] = in[i*Q + q]

@@ -6,9 +6,9 @@
 // into a G x G cell grid (counting sort, row-major cells) so that
 //   forward : one wave per observation gathers its W0^T rows (1 KiB coalesced each), neighbours in
 //             the sorted order re-use rows from L2; LayerNorm/ReLU/Dropout fused behind it;
-//   backward: every 4x8 knot block is OWNED by one workgroup that walks the observations of the
-//             cells overlapping the block's support box and accumulates phi^T dZ on the matrix
-//             cores — no atomics, fixed summation order.
+//   backward: every knot row of dW0^T is OWNED by one wave that walks the observations of the
+//             cells overlapping the knot's support square and gathers their dZ rows — no atomics,
+//             fixed summation order.
 // Integer bookkeeping (cell keys, sorted permutation, window origins) follows the bit-exact contract
 // written in include/stdadk.h (pinned by tests); phi uses the same arithmetic as rbf_build.hip.
 #include "window.h"
@@ -325,16 +325,16 @@ static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
   const int Kt_pad = (a.g.Kt + 3) & ~3;
   size_t lds = ((size_t)a.g.Kt * 64 * CPL + (FW_T / 64) * (LIST * 2 + Kt_pad)) * sizeof(float);
   auto kern = l1_window_fwd_kernel<CPL, LN, BASIS>;
-  // raise the dynamic-LDS cap once per process and kernel (never inside a stream capture: the
-  // engine runs its first step eagerly); 160 KiB is the CU's whole LDS
-  static bool attr_done = false;
-  if (!attr_done) {
+  // raise the dynamic-LDS cap when a launch needs more than any before it (never inside a stream
+  // capture: the engine runs its first step eagerly)
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("l1_window_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
+    attr_lds = lds;
   }
-  STDADK_LAUNCH(kern, dim3((unsigned)a.n_wg), dim3(FW_T), lds, st, a);
+  STDADK_LAUNCH_NAMED("l1_window_fwd_kernel", kern, dim3((unsigned)a.n_wg), dim3(FW_T), lds, st, a);
   STDADK_CHECK_LAUNCH("l1_window_forward");
   return 0;
 }
@@ -357,165 +357,109 @@ int l1_window_forward(const L1FwdArgs &a_in, int basis, bool ln, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward: dW0T[p+k, :] = sum_b phi[b,k] dZ[b,:], 4x8 knot block per workgroup
+// backward: dW0T[p+k, :] = sum_b phi[b,k] dZ[b,:]   — one wave OWNS one knot row
 // ---------------------------------------------------------------------------------------------
-constexpr int KBX = 4, KBY = 8, KB = KBX * KBY;   // 32 knots = one MFMA row tile
-constexpr int OT = 32;                            // observations per MFMA k-tile
-constexpr int MAX_SEG = 256;                      // cell rows a block may overlap (G <= 256)
+// The mirror image of the forward gather: a knot's support square overlaps a few cell rows of the
+// binning grid; each cell row is one contiguous range of sorted observations.  64 lanes evaluate
+// phi for 64 candidate observations at once, the non-zero ones are compacted into a per-wave list
+// and their dZ rows (1 KiB, coalesced) are accumulated 8 loads at a time.  No atomics, summation in
+// sorted-observation order => bitwise reproducible.  Coarse levels (most observations per knot) are
+// scheduled first.
+constexpr int BW_T = 256;        // 4 waves = 4 knots per workgroup
+constexpr int BW_LIST = 64;      // compacted candidates per flush
 
-constexpr int LCH = 512;                          // observations listed in LDS per pass
-
-template <int TN, int BASIS>
-__global__ __launch_bounds__(256) void l1_window_bwd_kernel(L1BwdArgs a) {
-  constexpr int H = 128 * TN;
-  __shared__ __attribute__((aligned(16))) float As[OT * KB];      // [obs][knot]
-  __shared__ __attribute__((aligned(16))) float Bs[OT * H];       // [obs][col]
-  __shared__ int seg_start[MAX_SEG], seg_pref[MAX_SEG + 1];
-  __shared__ int l_idx[LCH];
-  __shared__ float l_x[LCH], l_y[LCH];
-  __shared__ int s_kidx[KB];
-  __shared__ float s_box[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  // which level / block
-  int l = 0;
-  while (l + 1 < a.g.n_levels && (int)blockIdx.x >= a.blk_off[l + 1]) ++l;
-  const int bid = blockIdx.x - a.blk_off[l];
-  const int side = a.g.side[l];
-  const int bx = bid / a.nby[l], by = bid - bx * a.nby[l];
-
-  // this thread's knot (for the phi tile): i = tid & 31
-  const int ki = tid & (KB - 1);
-  const int kix = bx * KBX + ki / KBY, kiy = by * KBY + (ki % KBY);
-  const bool kvalid = kix < side && kiy < side;
-  const int kk = kvalid ? a.g.off[l] + kix * side + kiy : a.g.off[l];
-  const float kcx = a.g.centers[2 * kk], kcy = a.g.centers[2 * kk + 1];
-  const float ksc = knot_scale(a.g.bw[kk], a.g.cal);
-  if (tid < KB) s_kidx[tid] = kvalid ? kk : -1;
-  if (tid == 0) {
-    // support box of the block from the knot table itself (first / last valid knot per axis)
-    const int ix_lo = bx * KBX, ix_hi = min(bx * KBX + KBX - 1, side - 1);
-    const int iy_lo = by * KBY, iy_hi = min(by * KBY + KBY - 1, side - 1);
-    const int k00 = a.g.off[l] + ix_lo * side + iy_lo, k11 = a.g.off[l] + ix_hi * side + iy_hi;
-    const float r = a.g.bw[k00] * a.g.cal;     // support radius: r = dist/(bw*cal) < 1
-    s_box[0] = a.g.centers[2 * k00] - r;     s_box[1] = a.g.centers[2 * k11] + r;
-    s_box[2] = a.g.centers[2 * k00 + 1] - r; s_box[3] = a.g.centers[2 * k11 + 1] + r;
-  }
-  __syncthreads();
-  // cells overlapping the box, one cell of margin against rounding
+template <int CPL, int BASIS>
+__global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
+  constexpr int H = 64 * CPL;
+  __shared__ float lphi[BW_T / 64][BW_LIST + 8];
+  __shared__ int lidx[BW_T / 64][BW_LIST + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * (BW_T / 64) + wave;      // knots in table order: level 0 (coarsest) first
+  if (k >= a.g.Ks) return;
+  float *my_phi = lphi[wave];
+  int *my_idx = lidx[wave];
+  const float kcx = a.g.centers[2 * k], kcy = a.g.centers[2 * k + 1];
+  const float kbw = a.g.bw[k];
+  const float ksc = knot_scale(kbw, a.g.cal);
+  const float r = kbw * a.g.cal;                      // support radius
   const int G = a.G;
-  const int cx_lo = max(floor_clamp(s_box[0] * (float)G, G) - 1, 0);
-  const int cx_hi = min(floor_clamp(s_box[1] * (float)G, G) + 1, G - 1);
-  const int cy_lo = max(floor_clamp(s_box[2] * (float)G, G) - 1, 0);
-  const int cy_hi = min(floor_clamp(s_box[3] * (float)G, G) + 1, G - 1);
-  const int nseg = cx_hi - cx_lo + 1;
-  if (tid < nseg) {
-    const int cx = cx_lo + tid;
-    seg_start[tid] = a.cell_start[cx * G + cy_lo];
-    seg_pref[tid + 1] = a.cell_start[cx * G + cy_hi + 1] - seg_start[tid];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    seg_pref[0] = 0;
-    for (int i = 0; i < nseg; ++i) seg_pref[i + 1] += seg_pref[i];
-  }
-  __syncthreads();
-  const int total = seg_pref[nseg];
+  // cells overlapping the support square, one cell of margin against rounding
+  const int cx_lo = max(floor_clamp((kcx - r) * (float)G, G) - 1, 0);
+  const int cx_hi = min(floor_clamp((kcx + r) * (float)G, G) + 1, G - 1);
+  const int cy_lo = max(floor_clamp((kcy - r) * (float)G, G) - 1, 0);
+  const int cy_hi = min(floor_clamp((kcy + r) * (float)G, G) + 1, G - 1);
+  const uint64_t below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
 
-  f32x16 acc[TN];
+  float acc[CPL];
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const int wn = wave * (H / 4);     // this wave's first output column
-  const int ps = tid >> 3, part = tid & 7;     // dZ staging: 8 threads per observation row
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+  int n = 0;   // entries waiting in the list (wave-uniform)
 
-  float rphi[OT * KB / 256];
-  float4 rdz[H / 32];
-  // stage tile `tl` of the current list pass (n listed observations) into registers
-  auto load_tile = [&](int tl, int n) {
+  auto flush = [&](int cnt) {     // cnt is a multiple of 8
+    for (int e0 = 0; e0 < cnt; e0 += 8) {
+      float pv[8];
+      typename VecT<CPL>::T wv[8];
 #pragma unroll
-    for (int j = 0; j < OT * KB / 256; ++j) {
-      const int q = tl * OT + (tid >> 5) + 8 * j;
-      rphi[j] = (kvalid && q < n) ? phi_eval<BASIS>(l_x[q], l_y[q], kcx, kcy, ksc) : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        pv[e] = my_phi[e0 + e];
+        wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(a.dZ + (size_t)my_idx[e0 + e] * H + CPL * lane);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float *f = reinterpret_cast<const float *>(&wv[e]);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] = fmaf(pv[e], f[c], acc[c]);
+      }
     }
-    const int q = tl * OT + ps;
-    const bool ok = q < n;
-    const float4 *src = reinterpret_cast<const float4 *>(a.dZ + (size_t)(ok ? l_idx[q] : 0) * H);
-#pragma unroll
-    for (int j = 0; j < H / 32; ++j) rdz[j] = ok ? src[part + 8 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
-  for (int base = 0; base < total; base += LCH) {
-    const int n = min(LCH, total - base);
-    __syncthreads();                       // previous pass has finished reading the list
-    for (int q = tid; q < n; q += 256) {
-      const int pos = base + q;
-      int s = 0;
-      while (pos >= seg_pref[s + 1]) ++s;
-      const int idx = seg_start[s] + (pos - seg_pref[s]);
-      l_idx[q] = idx;
-      l_x[q] = a.xs[idx];
-      l_y[q] = a.ys[idx];
-    }
-    __syncthreads();
-    const int nt = (n + OT - 1) / OT;
-    load_tile(0, n);
-    for (int tl = 0; tl < nt; ++tl) {
-#pragma unroll
-      for (int j = 0; j < OT * KB / 256; ++j) As[((tid >> 5) + 8 * j) * KB + ki] = rphi[j];
-      {
-        float4 *dst = reinterpret_cast<float4 *>(Bs + ps * H);
-#pragma unroll
-        for (int j = 0; j < H / 32; ++j) dst[part + 8 * j] = rdz[j];
+  for (int cx = cx_lo; cx <= cx_hi; ++cx) {
+    const int s0 = a.cell_start[cx * G + cy_lo], s1 = a.cell_start[cx * G + cy_hi + 1];
+    for (int base = s0; base < s1; base += 64) {
+      const int i = base + lane;
+      float phi = 0.f;
+      if (i < s1) phi = phi_eval<BASIS>(a.xs[i], a.ys[i], kcx, kcy, ksc);
+      const uint64_t mask = __ballot(phi != 0.f);
+      const int m = __popcll(mask);
+      if (n + m > BW_LIST) {      // not enough room: flush the full groups of 8, keep the remainder
+        __builtin_amdgcn_wave_barrier();
+        const int full = n & ~7;
+        flush(full);
+        __builtin_amdgcn_wave_barrier();
+        const int rem = n - full;
+        float tp = 0.f; int ti = 0;
+        if (lane < rem) { tp = my_phi[full + lane]; ti = my_idx[full + lane]; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rem) { my_phi[lane] = tp; my_idx[lane] = ti; }
+        n = rem;
       }
-      __syncthreads();
-      if (tl + 1 < nt) load_tile(tl + 1, n);      // global loads in flight under the MFMAs below
-#pragma unroll
-      for (int s = 0; s < OT / 8; ++s) {
-        float fa[4], fb[TN][4];
-        const int h = lane >> 5, c = lane & 31;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fa[e] = As[(8 * s + 4 * h + e) * KB + c];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) fb[j][e] = Bs[(8 * s + 4 * h + e) * H + wn + j * 32 + c];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc[j], 0, 0, 0);
+      if (phi != 0.f) {
+        const int pos = n + __popcll(mask & below);
+        my_phi[pos] = phi;
+        my_idx[pos] = i;
       }
-      __syncthreads();
+      n += m;
     }
   }
+  // final flush, zero-padded to a multiple of 8 (row 0 of dZ is a valid address)
+  const int npad = (n + 7) & ~7;
+  if (lane < npad - n) { my_phi[n + lane] = 0.f; my_idx[n + lane] = 0; }
+  __builtin_amdgcn_wave_barrier();
+  flush(npad);
 
-  // every valid knot row of the block is written (zeros when no observation is in reach)
-  const int h = lane >> 5, c = lane & 31;
+  typename VecT<CPL>::T o;
+  float *f = reinterpret_cast<float *>(&o);
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int k = s_kidx[i];
-      if (k >= 0) a.dW0T[(size_t)(a.g.p + k) * H + wn + j * 32 + c] = acc[j][r];
-    }
+  for (int c = 0; c < CPL; ++c) f[c] = acc[c];
+  *reinterpret_cast<typename VecT<CPL>::T *>(a.dW0T + (size_t)(a.g.p + k) * H + CPL * lane) = o;
 }
 
 int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st) {
-  int nblk = 0;
-  for (int l = 0; l < a.g.n_levels; ++l) {
-    a.blk_off[l] = nblk;
-    a.nbx[l] = (int)ceil_div(a.g.side[l], KBX);
-    a.nby[l] = (int)ceil_div(a.g.side[l], KBY);
-    nblk += a.nbx[l] * a.nby[l];
-  }
-  a.blk_off[a.g.n_levels] = nblk;
-  STDADK_REQUIRE(a.G <= MAX_SEG, STDADK_E_ARG, "l1_window_backward: G too large");
-#define GO(TN_, BS_) STDADK_LAUNCH((l1_window_bwd_kernel<TN_, BS_>), dim3((unsigned)nblk), dim3(256), 0, st, a)
-  if (a.H == 256) { if (basis == STDADK_BASIS_WENDLAND) GO(2, 0); else GO(2, 2); }
-  else if (a.H == 128) { if (basis == STDADK_BASIS_WENDLAND) GO(1, 0); else GO(1, 2); }
+  STDADK_REQUIRE(a.G <= 256, STDADK_E_ARG, "l1_window_backward: G too large");
+  const unsigned grid = (unsigned)ceil_div(a.g.Ks, BW_T / 64);
+#define GO(CPL_, BS_) STDADK_LAUNCH((l1_window_bwd_kernel<CPL_, BS_>), dim3(grid), dim3(BW_T), 0, st, a)
+  if (a.H == 256) { if (basis == STDADK_BASIS_WENDLAND) GO(4, 0); else GO(4, 2); }
+  else if (a.H == 128) { if (basis == STDADK_BASIS_WENDLAND) GO(2, 0); else GO(2, 2); }
   else { set_error("l1_window_backward: H=%d unsupported", a.H); return STDADK_E_SHAPE; }
 #undef GO
   STDADK_CHECK_LAUNCH("l1_window_backward");

@@ -86,7 +86,8 @@ _SIGNATURES = {
     "stdadk_gemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
-    "stdadk_sumsq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "stdadk_sumsq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stdadk_step_advance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "stdadk_adamw_ema_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_float, C.c_void_p, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float,
@@ -328,18 +329,22 @@ def mse(y_pred, y, grad_scale, dY=None, loss_sum=None):
 SUMSQ_PARTS = 256
 
 
-def sumsq(g, parts):
-    """parts[0:256] = partial sums of g^2 (`parts` is a 256-float slice, fully overwritten)."""
+def sumsq(g, parts, step_inc=None):
+    """parts[0:256] = partial sums of g^2 (`parts` is a 256-float slice, fully overwritten);
+    step_inc (device int32) is advanced by one when given."""
     if parts.numel() != SUMSQ_PARTS:
         raise RuntimeError(f"sumsq: parts must hold {SUMSQ_PARTS} floats")
-    rc = lib().stdadk_sumsq_f32(_dev(g, "g"), g.numel(), _dev(parts, "parts"), _stream())
+    rc = lib().stdadk_sumsq_f32(_dev(g, "g"), g.numel(), _dev(parts, "parts"), _dev(step_inc, "step_inc"),
+                                _stream())
     _check(rc, "stdadk_sumsq_f32")
+
+
+def step_advance(step_dev):
+    _check(lib().stdadk_step_advance(_dev(step_dev, "step_dev"), _stream()), "stdadk_step_advance")
 
 
 def adamw_ema(p, g, m, v, ema, lr, betas, eps, weight_decay, step, max_norm=0.0, sumsq_parts=None,
               grad_mul=1.0, ema_decay=0.0, lr_dev=None, step_dev=None):
-    if step_dev is not None and step_dev.numel() < 2:
-        raise RuntimeError("adamw_ema: step_dev must be an int32 tensor of 2 elements")
     rc = lib().stdadk_adamw_ema_f32(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"),
                                     _dev(ema, "ema"), p.numel(), lr, _dev(lr_dev, "lr_dev"),
                                     betas[0], betas[1], eps, weight_decay, int(step),

@@ -89,7 +89,7 @@ class TrainStep:
         self.loss_sum = torch.zeros(1, device=self.dev)       # running sum of squared errors
         self.sumsq = torch.zeros(N.SUMSQ_PARTS, device=self.dev)
         self.lr_dev = torch.full((1,), self.lr, device=self.dev)
-        self.step_dev = torch.zeros(2, device=self.dev, dtype=torch.int32)
+        self.step_dev = torch.zeros(1, device=self.dev, dtype=torch.int32)
         self.seed = 0x5DEECE66D
         self.rows_seen = 0
         # distributed
@@ -121,7 +121,9 @@ class TrainStep:
         if self.distributed:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
         if self.grad_clip > 0:
-            N.sumsq(self.grad, self.sumsq)
+            N.sumsq(self.grad, self.sumsq, step_inc=self.step_dev)
+        else:
+            N.step_advance(self.step_dev)
         N.adamw_ema(self.flat, self.grad, self.m, self.v, self.ema, self.lr, self.betas, self.eps,
                     self.wd, self.step_count + 1, max_norm=self.grad_clip, sumsq_parts=self.sumsq,
                     ema_decay=self.ema_decay, lr_dev=self.lr_dev, step_dev=self.step_dev)
