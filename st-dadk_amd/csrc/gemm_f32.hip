@@ -33,6 +33,9 @@ struct TileGeom {
 template <int ROWS, bool KM, int VEC>
 __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t ld, int r0, int nrows,
                                           int k0, int kend, float *reg) {
+  // Every load is UNCONDITIONAL from a clamped, always-valid address (the tile's first row / k when
+  // out of range) and masked in registers afterwards: a conditional load gets its own branch and a
+  // vmcnt(0), which would serialise the register-prefetch pipeline of the K loop.
   const int tid = threadIdx.x;
   constexpr int N_VEC = TileGeom<ROWS, KM>::ELEMS / VEC;
   if (!KM) {
@@ -40,24 +43,24 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t l
     constexpr int RPP = GT / VPR;       // rows per pass
 #pragma unroll
     for (int i = 0; i < N_VEC; ++i) {
-      int row = tid / VPR + i * RPP;
-      int k = k0 + (tid % VPR) * VEC;
-      bool rok = (r0 + row) < nrows;
-      const float *src = P + (int64_t)(r0 + row) * ld + k;
+      const int row = tid / VPR + i * RPP;
+      const int k = k0 + (tid % VPR) * VEC;
+      const bool rok = (r0 + row) < nrows;
+      const bool ok = rok && k < kend;
+      const float *src = P + (int64_t)(rok ? r0 + row : r0) * ld + (k < kend ? k : k0);
       if (VEC == 4) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rok && k < kend) v = *reinterpret_cast<const float4 *>(src);
-        reg[i * 4 + 0] = (k + 0 < kend) ? v.x : 0.f;
-        reg[i * 4 + 1] = (k + 1 < kend) ? v.y : 0.f;
-        reg[i * 4 + 2] = (k + 2 < kend) ? v.z : 0.f;
-        reg[i * 4 + 3] = (k + 3 < kend) ? v.w : 0.f;
+        const float4 v = *reinterpret_cast<const float4 *>(src);
+        reg[i * 4 + 0] = (ok && k + 0 < kend) ? v.x : 0.f;
+        reg[i * 4 + 1] = (ok && k + 1 < kend) ? v.y : 0.f;
+        reg[i * 4 + 2] = (ok && k + 2 < kend) ? v.z : 0.f;
+        reg[i * 4 + 3] = (ok && k + 3 < kend) ? v.w : 0.f;
       } else if (VEC == 2) {
-        float2 v = make_float2(0.f, 0.f);
-        if (rok && k < kend) v = *reinterpret_cast<const float2 *>(src);
-        reg[i * 2 + 0] = (k + 0 < kend) ? v.x : 0.f;
-        reg[i * 2 + 1] = (k + 1 < kend) ? v.y : 0.f;
+        const float2 v = *reinterpret_cast<const float2 *>(src);
+        reg[i * 2 + 0] = (ok && k + 0 < kend) ? v.x : 0.f;
+        reg[i * 2 + 1] = (ok && k + 1 < kend) ? v.y : 0.f;
       } else {
-        reg[i] = (rok && k < kend) ? *src : 0.f;
+        const float v = *src;
+        reg[i] = ok ? v : 0.f;
       }
     }
   } else {
@@ -65,24 +68,24 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t l
     constexpr int KPP = GT / VPR;       // k-rows per pass
 #pragma unroll
     for (int i = 0; i < N_VEC; ++i) {
-      int kk = tid / VPR + i * KPP;
-      int r = r0 + (tid % VPR) * VEC;
-      bool kok = (k0 + kk) < kend;
-      const float *src = P + (int64_t)(k0 + kk) * ld + r;
+      const int kk = tid / VPR + i * KPP;
+      const int r = r0 + (tid % VPR) * VEC;
+      const bool kok = (k0 + kk) < kend;
+      const bool ok = kok && r < nrows;
+      const float *src = P + (int64_t)(kok ? k0 + kk : k0) * ld + (r < nrows ? r : r0);
       if (VEC == 4) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kok && r < nrows) v = *reinterpret_cast<const float4 *>(src);
-        reg[i * 4 + 0] = (r + 0 < nrows) ? v.x : 0.f;
-        reg[i * 4 + 1] = (r + 1 < nrows) ? v.y : 0.f;
-        reg[i * 4 + 2] = (r + 2 < nrows) ? v.z : 0.f;
-        reg[i * 4 + 3] = (r + 3 < nrows) ? v.w : 0.f;
+        const float4 v = *reinterpret_cast<const float4 *>(src);
+        reg[i * 4 + 0] = (ok && r + 0 < nrows) ? v.x : 0.f;
+        reg[i * 4 + 1] = (ok && r + 1 < nrows) ? v.y : 0.f;
+        reg[i * 4 + 2] = (ok && r + 2 < nrows) ? v.z : 0.f;
+        reg[i * 4 + 3] = (ok && r + 3 < nrows) ? v.w : 0.f;
       } else if (VEC == 2) {
-        float2 v = make_float2(0.f, 0.f);
-        if (kok && r < nrows) v = *reinterpret_cast<const float2 *>(src);
-        reg[i * 2 + 0] = (r + 0 < nrows) ? v.x : 0.f;
-        reg[i * 2 + 1] = (r + 1 < nrows) ? v.y : 0.f;
+        const float2 v = *reinterpret_cast<const float2 *>(src);
+        reg[i * 2 + 0] = (ok && r + 0 < nrows) ? v.x : 0.f;
+        reg[i * 2 + 1] = (ok && r + 1 < nrows) ? v.y : 0.f;
       } else {
-        reg[i] = (kok && r < nrows) ? *src : 0.f;
+        const float v = *src;
+        reg[i] = ok ? v : 0.f;
       }
     }
   }

@@ -39,6 +39,7 @@ struct Plan {
   size_t dA, dZ;            // [B][hmax] each
   size_t part, part_floats; // column-sum partials
   size_t dZl[STDADK_MAX_HIDDEN], partl[STDADK_MAX_HIDDEN];   // fused tail: per-layer dZ and partials
+  size_t wT[STDADK_MAX_HIDDEN];                              // fused tail: W_l^T scratch (l >= 1)
   // step-level buffers
   size_t feats; int64_t ldf;           // dense: materialised features
   size_t psi; int ld_psi;              // window: temporal basis [B][ld_psi]
@@ -102,6 +103,7 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
   for (int l = 0; l < d->n_hidden; ++l) {
     p->dZl[l] = take((size_t)B * d->hidden[l]);
     p->partl[l] = take((size_t)ceil_div(B, TAIL_ROWS) * 3 * d->hidden[l]);
+    p->wT[l] = take(l > 0 ? (size_t)d->hidden[l] * d->hidden[l - 1] : 1);
   }
   p->feats = p->psi = p->ypred = p->dY = 0;
   p->ldf = 0; p->ld_psi = 0; p->G = 0;
@@ -547,6 +549,7 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
     a.y = c.mse_y; a.grad_scale = c.mse_scale; a.dY = c.mse_dY; a.loss_sum = c.mse_loss;
     a.layernorm = d->layernorm; a.eps = d->ln_eps; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
     c.mse_done = c.mse_y != nullptr;
+    { const char *e = getenv("STDADK_TAIL_DEBUG"); a.debug = e ? atoi(e) : 0; }
     return tail_forward(a, st);
   }
   for (int l = l0; l < L; ++l) {
@@ -594,6 +597,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
       a.L[l] = tail_layer(c, l);
       a.dZ[l] = ws + pl.dZl[l];
       a.part[l] = ws + pl.partl[l];
+      a.WT[l] = ws + pl.wT[l];
     }
     STDADK_REQUIRE(G->W[L] && G->b[L], STDADK_E_ARG, "mlp_backward: output layer grads NULL");
     a.B = (int)B; a.Wo = P->W[L]; a.Q = Q; a.dY = dY;

@@ -12,14 +12,93 @@ namespace stdadk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TT = 256;                       // threads per workgroup (4 waves)
+constexpr int NW = 16;                        // waves per workgroup (4 per SIMD): the phases are latency-bound at
+                                              // 16 rows per workgroup, more waves = more loads in flight
+constexpr int TT = 64 * NW;                   // threads per workgroup
+constexpr int RPW = TAIL_ROWS / NW;           // rows per wave in the row-wise phases
+constexpr int MAX_NI = TAIL_MAX_W / 16 / NW;  // N tiles per wave
 constexpr int R = TAIL_ROWS;                  // 16 rows
 constexpr int ACT_LD = TAIL_MAX_W + 4;        // activation row stride in LDS (floats)
-constexpr int WF_LD = 36;                     // forward W chunk: [n][32 k] row stride
-constexpr int WK_LD = TAIL_MAX_W + 16;        // backward W chunk: [32 k][n] row stride
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+
+// acc[i] (N-tile t = wave + NW i) += A[16 x K] (LDS, row stride ACT_LD) * Wn[N x K]^T where Wn is
+// row-major [N][K] in global memory (K contiguous).  M = 16 is the GEMV-like regime: every wave
+// streams ITS OWN slice of W straight into VGPRs (no LDS staging, no workgroup barrier in the K
+// loop), two 32-deep chunks in flight, 64-byte row pieces per lane group.
+template <int NI>
+struct BFrag { float4 v[2 * NI]; };     // [j*NI + i] : chunk fragment of this lane
+
+// Loads are UNCONDITIONAL from clamped (always valid) addresses and never masked in registers: a
+// conditional load gets its own branch + vmcnt(0), and a select on the loaded value drags the wait
+// in front of the MFMAs of the previous chunk.  The number of N tiles of this wave (NI) is a
+// template parameter and the K-half test is scalar, so the MFMA stream has no exec-masked branches.
+template <int NI>
+__device__ __forceinline__ void load_bfrag(BFrag<NI> &f, const float *__restrict__ Wn, int K, int c, int wave,
+                                           int c16, int q) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = 32 * c + 16 * j + 4 * q;
+    const int kc = k < K ? k : 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = 16 * (wave + NW * i) + c16;         // < N by construction of NI
+      f.v[j * NI + i] = *reinterpret_cast<const float4 *>(Wn + (size_t)n * K + kc);
+    }
+  }
+}
+
+template <int NI>
+__device__ __forceinline__ void mma_chunk(f32x4 *acc, const BFrag<NI> &f, const float *__restrict__ A, int K, int c,
+                                          int c16, int q) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (32 * c + 16 * j < K) {          // scalar: K is a multiple of 16, a 16-deep half is all in or out
+      const float4 av = *reinterpret_cast<const float4 *>(A + c16 * ACT_LD + 32 * c + 16 * j + 4 * q);
+      const float af[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {   // consecutive MFMAs hit different accumulators
+          const float4 bv = f.v[j * NI + i];
+          const float bf[4] = {bv.x, bv.y, bv.z, bv.w};
+          acc[i] = mfma16(af[e], bf[e], acc[i]);
+        }
+      }
+    }
+  }
+}
+
+template <int NI>
+__device__ __forceinline__ void gemm16_ni(f32x4 *acc, const float *__restrict__ A, const float *__restrict__ Wn,
+                                          int K, int wave, int c16, int q) {
+  const int nchunk = (K + 31) >> 5;
+  BFrag<NI> f0, f1;
+  load_bfrag<NI>(f0, Wn, K, 0, wave, c16, q);
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 1 < nchunk) load_bfrag<NI>(f1, Wn, K, c + 1, wave, c16, q);
+    mma_chunk<NI>(acc, f0, A, K, c, c16, q);
+    if (c + 1 < nchunk) {
+      if (c + 2 < nchunk) load_bfrag<NI>(f0, Wn, K, c + 2, wave, c16, q);
+      mma_chunk<NI>(acc, f1, A, K, c + 1, c16, q);
+    }
+  }
+}
+
+// acc[i] (N-tile t = wave + NW i) += A[16 x K] (LDS, row stride ACT_LD) * Wn[N x K]^T where Wn is
+// row-major [N][K] in global memory (K contiguous).  M = 16 is the GEMV-like regime: every wave
+// streams ITS OWN slice of W straight into VGPRs (no LDS staging, no workgroup barrier in the K
+// loop), two 32-deep chunks in flight, 64-byte row pieces per lane group.
+__device__ __forceinline__ void gemm16(f32x4 *acc, const float *__restrict__ A, const float *__restrict__ Wn, int N,
+                                       int K, int wave, int c16, int q) {
+  const int NT = N >> 4;
+  const int ni = (NT - wave + NW - 1) / NW;   // tiles wave, wave+NW, ... < NT   (wave is scalar)
+  static_assert(MAX_NI <= 2, "dispatch below assumes at most 2 tiles per wave");
+  if (MAX_NI >= 2 && ni >= 2) gemm16_ni<(MAX_NI >= 2 ? 2 : 1)>(acc, A, Wn, K, wave, c16, q);
+  else if (ni >= 1) gemm16_ni<1>(acc, A, Wn, K, wave, c16, q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -28,20 +107,32 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *act0 = smem, *act1 = smem + R * ACT_LD;
-  float *wb = smem + 2 * R * ACT_LD;                 // [2][TAIL_MAX_W * WF_LD]
   __shared__ float red[TT / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = blockIdx.x * R;
   for (int i = tid; i < 2 * R * ACT_LD; i += TT) smem[i] = 0.f;   // pads must be finite (x0 later)
   __syncthreads();
   {
-    const int v4 = a.h_in >> 2;
-    for (int idx = tid; idx < R * v4; idx += TT) {
+    // input tile: unconditional loads from clamped rows (rows >= B duplicate the last row; nothing
+    // computed for them is ever stored), 4 per thread in flight
+    const int v4 = a.h_in >> 2;            // <= 64 float4 per row => R*v4 <= 1024
+    constexpr int NLD = 1024 / TT;
+    float4 tv[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = min(tid + TT * i, R * v4 - 1);
       const int row = idx / v4, c4 = idx - row * v4;
-      if (row0 + row < a.B)
-        *reinterpret_cast<float4 *>(act0 + row * ACT_LD + 4 * c4) =
-            *reinterpret_cast<const float4 *>(a.a_in + (size_t)(row0 + row) * a.h_in + 4 * c4);
+      tv[i] = *reinterpret_cast<const float4 *>(a.a_in + (size_t)min(row0 + row, a.B - 1) * a.h_in + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + TT * i;
+      if (idx < R * v4) {
+        const int row = idx / v4, c4 = idx - row * v4;
+        *reinterpret_cast<float4 *>(act0 + row * ACT_LD + 4 * c4) = tv[i];
+      }
     }
   }
   __syncthreads();
@@ -52,50 +143,15 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   for (int li = 0; li < a.n_layers; ++li) {
     const TailLayer &L = a.L[li];
     const int h = L.h, hp = L.hp;
-    const int NT = h >> 4, nchunk = (hp + 31) >> 5;
-    f32x4 acc[4];
+    const int NT = h >> 4;
+    f32x4 acc[MAX_NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 wreg[8];
-    auto load_chunk = [&](int c) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = tid + TT * i;
-        const int n = idx >> 3, k = 32 * c + 4 * (idx & 7);
-        wreg[i] = (n < h && k < hp) ? *reinterpret_cast<const float4 *>(L.W + (size_t)n * hp + k)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    load_chunk(0);
-    for (int c = 0; c < nchunk; ++c) {
-      float *wbuf = wb + (c & 1) * (TAIL_MAX_W * WF_LD);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = tid + TT * i;
-        *reinterpret_cast<float4 *>(wbuf + (idx >> 3) * WF_LD + 4 * (idx & 7)) = wreg[i];
-      }
-      __syncthreads();
-      if (c + 1 < nchunk) load_chunk(c + 1);      // next chunk's loads fly under the MFMAs
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float4 av = *reinterpret_cast<const float4 *>(cur + c16 * ACT_LD + 32 * c + 16 * j + 4 * q);
-        const float af[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int t = wave + 4 * i;
-          if (t < NT) {
-            const float4 bv = *reinterpret_cast<const float4 *>(wbuf + (16 * t + c16) * WF_LD + 16 * j + 4 * q);
-            const float bf[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i] = mfma16(af[e], bf[e], acc[i]);
-          }
-        }
-      }
-    }
+    for (int i = 0; i < MAX_NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!(a.debug & 1)) gemm16(acc, cur, L.W, h, hp, wave, c16, q);
     // z = acc + bias into the other activation buffer
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = wave + 4 * i;
+    for (int i = 0; i < MAX_NI; ++i) {
+      const int t = wave + NW * i;
       if (t < NT) {
         const int col = 16 * t + c16;
         const float bv = L.b[col];
@@ -104,10 +160,19 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
       }
     }
     __syncthreads();
-    // LayerNorm -> ReLU -> Dropout, wave w owns rows 4w .. 4w+3
+    // LayerNorm -> ReLU -> Dropout, wave w owns rows RPW*w .. RPW*w+RPW-1.  gamma/beta are loaded once per
+    // layer from clamped columns (no conditional loads: each would cost its own L2 round trip).
+    float gv[4], bev[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = 4 * wave + rr;
+    for (int cc = 0; cc < 4; ++cc) {
+      const int colc = min(lane + 64 * cc, h - 1);
+      gv[cc] = a.layernorm ? L.g[colc] : 1.f;
+      bev[cc] = a.layernorm ? L.be[colc] : 0.f;
+    }
+    if (!(a.debug & 2))
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = RPW * wave + rr;
       const int grow = row0 + row;
       float z[4];
       float s = 0.f;
@@ -122,22 +187,24 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
         mean = wave_sum(s) / (float)h;
         float sq = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-          if (lane + 64 * cc < h) { float d = z[cc] - mean; sq += d * d; }
+        for (int cc = 0; cc < 4; ++cc) {
+          const float d = (lane + 64 * cc < h) ? z[cc] - mean : 0.f;
+          sq += d * d;
+        }
         rs = 1.0f / sqrtf(wave_sum(sq) / (float)h + a.eps);
         if (lane == 0 && grow < a.B) L.rstd[grow] = rs;
       }
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int col = lane + 64 * cc;
+        const float xh = a.layernorm ? (z[cc] - mean) * rs : z[cc];
+        const float u = fmaf(xh, gv[cc], bev[cc]);
+        float v = fmaxf(u, 0.f);
+        if (a.drop_p > 0.f) {
+          const bool keep = drop_keep(seed, L.layer_id, (int64_t)grow * h + col, a.drop_p);
+          v = keep ? v * keep_scale : 0.f;
+        }
         if (col < h) {
-          const float xh = a.layernorm ? (z[cc] - mean) * rs : z[cc];
-          const float u = a.layernorm ? fmaf(xh, L.g[col], L.be[col]) : xh;
-          float v = fmaxf(u, 0.f);
-          if (a.drop_p > 0.f) {
-            const bool keep = drop_keep(seed, L.layer_id, (int64_t)grow * h + col, a.drop_p);
-            v = keep ? v * keep_scale : 0.f;
-          }
           nxt[row * ACT_LD + col] = v;
           if (grow < a.B) {
             L.xhat[(size_t)grow * h + col] = xh;
@@ -153,9 +220,10 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   // output layer (+ MSE): y[row][qq] = a_last[row,:] . Wo[qq,:] + bo[qq]
   const int hl = a.n_layers ? a.L[a.n_layers - 1].h : a.h_in;
   float lsum = 0.f;
+  if (!(a.debug & 4))
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int row = 4 * wave + rr;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = RPW * wave + rr;
     const int grow = row0 + row;
     for (int qq = 0; qq < a.Q; ++qq) {
       float s = 0.f;
@@ -175,7 +243,12 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   if (a.y && a.loss_sum) {
     if (lane == 0) red[wave] = lsum;
     __syncthreads();
-    if (tid == 0) atomicAdd(a.loss_sum, (red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w];
+      atomicAdd(a.loss_sum, t);
+    }
   }
 }
 
@@ -185,10 +258,10 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
 __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *d0 = smem, *d1 = smem + R * ACT_LD;
-  float *wb = smem + 2 * R * ACT_LD;                 // [2][32 * WK_LD]
-  float *red = wb + 2 * 32 * WK_LD;                  // [3][4][256]
-  float *sdy = red + 3 * 4 * 256;                    // [R][TAIL_MAXQ]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *red = smem + 2 * R * ACT_LD;                // [3][NW][256]
+  float *sdy = red + 3 * NW * 256;                   // [R][TAIL_MAXQ]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = blockIdx.x * R;
   for (int i = tid; i < 2 * R * ACT_LD; i += TT) smem[i] = 0.f;
@@ -236,52 +309,62 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   for (int li = a.n_layers - 1; li >= 0; --li) {
     const TailLayer &L = a.L[li];
     const int h = L.h;
-    // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows 4w .. 4w+3 of this wave
-    float pg[4], pb[4], pz[4];
+    // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows 4w .. 4w+3 of this wave.
+    // All global loads of the phase (xhat of 4 rows, gamma, beta, rstd) are issued up front from
+    // clamped addresses, unconditionally, so they share one L2 round trip.
+    float pg[4], pb[4], pz[4], gv[4], bev[4], xv[RPW][4], rsv[RPW];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) pg[cc] = pb[cc] = pz[cc] = 0.f;
+    for (int cc = 0; cc < 4; ++cc) {
+      pg[cc] = pb[cc] = pz[cc] = 0.f;
+      const int colc = min(lane + 64 * cc, h - 1);
+      gv[cc] = a.layernorm ? L.g[colc] : 1.f;
+      bev[cc] = a.layernorm ? L.be[colc] : 0.f;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = 4 * wave + rr;
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int growc = min(row0 + RPW * wave + rr, a.B - 1);
+        xv[rr][cc] = L.xhat[(size_t)growc * h + colc];
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) rsv[rr] = a.layernorm ? L.rstd[min(row0 + RPW * wave + rr, a.B - 1)] : 1.f;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = RPW * wave + rr;
       const int grow = row0 + row;
       const bool valid = grow < a.B;
-      float xh[4], dxh[4];
+      float dxh[4];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int col = lane + 64 * cc;
-        xh[cc] = 0.f; dxh[cc] = 0.f;
-        if (col < h && valid) {
-          const float x = L.xhat[(size_t)grow * h + col];
-          const float u = a.layernorm ? fmaf(x, L.g[col], L.be[col]) : x;
-          float d = cur[row * ACT_LD + col];
-          if (a.drop_p > 0.f) {
-            const bool keep = drop_keep(seed, L.layer_id, (int64_t)grow * h + col, a.drop_p);
-            d = keep ? d * keep_scale : 0.f;
-          }
-          d = u > 0.f ? d : 0.f;
-          xh[cc] = x;
-          if (a.layernorm) {
-            pg[cc] += d * x;
-            pb[cc] += d;
-            d *= L.g[col];
-            s1 += d;
-            s2 += d * x;
-          }
-          dxh[cc] = d;
+        const bool ok = valid && col < h;
+        const float x = xv[rr][cc];
+        const float u = fmaf(x, gv[cc], bev[cc]);
+        float d = cur[row * ACT_LD + min(col, TAIL_MAX_W - 1)];
+        if (a.drop_p > 0.f) {
+          const bool keep = drop_keep(seed, L.layer_id, (int64_t)grow * h + col, a.drop_p);
+          d = keep ? d * keep_scale : 0.f;
         }
+        d = (ok && u > 0.f) ? d : 0.f;
+        if (a.layernorm) {
+          pg[cc] += d * x;
+          pb[cc] += d;
+          d *= gv[cc];
+          s1 += d;
+          s2 += d * x;
+        }
+        dxh[cc] = d;
       }
-      float rs = 1.f, m1 = 0.f, m2 = 0.f;
+      float m1 = 0.f, m2 = 0.f;
       if (a.layernorm) {
         m1 = wave_sum(s1) / (float)h;
         m2 = wave_sum(s2) / (float)h;
-        rs = valid ? L.rstd[grow] : 0.f;
       }
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int col = lane + 64 * cc;
         if (col < h) {
-          const float dz = (a.layernorm && valid) ? rs * (dxh[cc] - m1 - xh[cc] * m2) : dxh[cc];
+          const float dz = (a.layernorm && valid) ? rsv[rr] * (dxh[cc] - m1 - xv[rr][cc] * m2) : dxh[cc];
           cur[row * ACT_LD + col] = dz;
           if (valid) a.dZ[li][(size_t)grow * h + col] = dz;
           pz[cc] += dz;
@@ -291,65 +374,33 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
     // column partials of this workgroup's 16 rows
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-      red[(0 * 4 + wave) * 256 + lane + 64 * cc] = pg[cc];
-      red[(1 * 4 + wave) * 256 + lane + 64 * cc] = pb[cc];
-      red[(2 * 4 + wave) * 256 + lane + 64 * cc] = pz[cc];
+      red[(0 * NW + wave) * 256 + lane + 64 * cc] = pg[cc];
+      red[(1 * NW + wave) * 256 + lane + 64 * cc] = pb[cc];
+      red[(2 * NW + wave) * 256 + lane + 64 * cc] = pz[cc];
     }
     __syncthreads();
     if (tid < h) {
       float *pbase = a.part[li] + (size_t)blockIdx.x * 3 * h;
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        pbase[k * h + tid] = (red[(k * 4 + 0) * 256 + tid] + red[(k * 4 + 1) * 256 + tid]) +
-                             (red[(k * 4 + 2) * 256 + tid] + red[(k * 4 + 3) * 256 + tid]);
+      for (int k = 0; k < 3; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[(k * NW + w) * 256 + tid];
+        pbase[k * h + tid] = t;
+      }
     }
-    if (li == 0) break;
-    // ---- (b) dA_prev[16 x hp] = dZ[16 x h] W[h x hp]
+    if (li == 0) break;   // (the partials above are published by the barrier inside part (b) / kernel end)
+    // ---- (b) dA_prev[16 x hp] = dZ[16 x h] W[h x hp], with W^T ([hp][h], K contiguous) as the B operand
     const int hp = L.hp;
-    const int NT = hp >> 4, nchunk = (h + 31) >> 5, v4 = hp >> 2;
-    f32x4 acc[4];
+    const int NT = hp >> 4;
+    f32x4 acc[MAX_NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 wreg[8];
-    auto load_chunk = [&](int c) {
+    for (int i = 0; i < MAX_NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                 // every wave's dZ rows are in `cur`
+    gemm16(acc, cur, a.WT[li], hp, h, wave, c16, q);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = tid + TT * i;
-        const int kk = idx / v4, c4 = idx - kk * v4;
-        wreg[i] = (kk < 32 && 32 * c + kk < h)
-                      ? *reinterpret_cast<const float4 *>(L.W + (size_t)(32 * c + kk) * hp + 4 * c4)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    load_chunk(0);
-    for (int c = 0; c < nchunk; ++c) {
-      float *wbuf = wb + (c & 1) * (32 * WK_LD);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = tid + TT * i;
-        const int kk = idx / v4, c4 = idx - kk * v4;
-        if (kk < 32) *reinterpret_cast<float4 *>(wbuf + kk * WK_LD + 4 * c4) = wreg[i];
-      }
-      __syncthreads();
-      if (c + 1 < nchunk) load_chunk(c + 1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float4 av = *reinterpret_cast<const float4 *>(cur + c16 * ACT_LD + 32 * c + 16 * j + 4 * q);
-        const float af[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int t = wave + 4 * i;
-          if (t < NT) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[i] = mfma16(af[e], wbuf[(16 * j + 4 * q + e) * WK_LD + 16 * t + c16], acc[i]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = wave + 4 * i;
+    for (int i = 0; i < MAX_NI; ++i) {
+      const int t = wave + NW * i;
       if (t < NT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) nxt[(4 * q + r) * ACT_LD + 16 * t + c16] = acc[i][r];
@@ -358,6 +409,22 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
     __syncthreads();
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
+}
+
+// WT[n][k] = W[k][n] for the tail layers (h x hp -> hp x h), one launch for all of them
+struct TransArgs { int n; const float *W[TAIL_MAX_LAYERS]; float *WT[TAIL_MAX_LAYERS]; int h[TAIL_MAX_LAYERS], hp[TAIL_MAX_LAYERS]; };
+__global__ __launch_bounds__(256) void tail_transpose_kernel(TransArgs a) {
+  __shared__ float tile[32][33];
+  const int li = blockIdx.z;
+  const int h = a.h[li], hp = a.hp[li];
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;     // W[k][n], k < h, n < hp
+  if (k0 >= h || n0 >= hp) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (k0 + r < h && n0 + tx < hp) ? a.W[li][(size_t)(k0 + r) * hp + n0 + tx] : 0.f;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (n0 + r < hp && k0 + tx < h) a.WT[li][(size_t)(n0 + r) * h + k0 + tx] = tile[tx][r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -369,8 +436,8 @@ bool tail_supported(const stdadk_mlp_desc *d, int first_layer) {
   return true;
 }
 
-static size_t fwd_lds() { return (2 * R * ACT_LD + 2 * TAIL_MAX_W * WF_LD) * sizeof(float); }
-static size_t bwd_lds() { return (2 * R * ACT_LD + 2 * 32 * WK_LD + 3 * 4 * 256 + R * TAIL_MAXQ) * sizeof(float); }
+static size_t fwd_lds() { return (2 * R * ACT_LD) * sizeof(float); }
+static size_t bwd_lds() { return (2 * R * ACT_LD + 3 * NW * 256 + R * TAIL_MAXQ) * sizeof(float); }
 
 int tail_forward(const TailFwdArgs &a, hipStream_t st) {
   static bool attr_done = false;
@@ -386,6 +453,21 @@ int tail_forward(const TailFwdArgs &a, hipStream_t st) {
 }
 
 int tail_backward(const TailBwdArgs &a, hipStream_t st) {
+  if (a.n_layers > 1) {
+    TransArgs t;
+    t.n = a.n_layers - 1;
+    int hmax = 0, hpmax = 0;
+    for (int li = 1; li < a.n_layers; ++li) {
+      t.W[li - 1] = a.L[li].W; t.WT[li - 1] = a.WT[li];
+      t.h[li - 1] = a.L[li].h; t.hp[li - 1] = a.L[li].hp;
+      hmax = a.L[li].h > hmax ? a.L[li].h : hmax;
+      hpmax = a.L[li].hp > hpmax ? a.L[li].hp : hpmax;
+    }
+    for (int li = t.n; li < TAIL_MAX_LAYERS; ++li) { t.W[li] = nullptr; t.WT[li] = nullptr; t.h[li] = t.hp[li] = 0; }
+    STDADK_LAUNCH(tail_transpose_kernel, dim3((unsigned)ceil_div(hpmax, 32), (unsigned)ceil_div(hmax, 32), (unsigned)t.n),
+                  dim3(256), 0, st, t);
+    STDADK_CHECK_LAUNCH("tail_transpose");
+  }
   static bool attr_done = false;
   if (!attr_done) {   // once per process, never inside a stream capture (the first step runs eagerly)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel),

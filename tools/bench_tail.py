@@ -1,0 +1,29 @@
+"""Ablation timing of the fused tail forward kernel (debug env STDADK_TAIL_DEBUG)."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "st-dadk_amd")):
+    sys.path.insert(0, p)
+import torch
+from stnf.models import STInterpMLP
+from stnf.engine import TrainStep
+from stnf import _native as N
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+m = STInterpMLP(k_spatial_centers=[1024, 4096, 5184], dropout=float(os.environ.get("DROPOUT", "0.1"))).to(dev)
+m.train()
+eng = TrainStep(m, ema_decay=0.999, max_batch=B)
+g = torch.Generator().manual_seed(1)
+coords = torch.rand(B, 2, generator=g).to(dev); t = torch.rand(B, generator=g).to(dev); y = torch.randn(B, 1, generator=g).to(dev)
+for _ in range(3):
+    eng._enqueue(None, coords, t, y, B, B)
+torch.cuda.synchronize()
+N.profile_enable(True)
+for _ in range(10):
+    eng._enqueue(None, coords, t, y, B, B)
+recs = N.profile_collect()
+N.profile_enable(False)
+agg = {}
+for n, ms in recs:
+    a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += ms
+print("debug", os.environ.get("STDADK_TAIL_DEBUG", "0"), {k: round(v[1] / v[0] * 1e3, 1) for k, v in agg.items() if "tail" in k or "window" in k})
