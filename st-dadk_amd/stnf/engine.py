@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native as N
+from . import distributed as D
 
 
 def flatten_parameters(model, transpose_first=True):
@@ -116,10 +117,10 @@ class TrainStep:
         Q = self.model.output_dim
         # d(mean over the GLOBAL batch)/dparams: each rank scales by 1/global_rows, the all-reduce SUMs
         N.train_fwd_bwd(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, B,
-                        1.0 / (global_rows * Q), self.loss_sum, None, self.ws, st.flags,
+                        D.grad_scale(global_rows, Q), self.loss_sum, None, self.ws, st.flags,
                         seed=self.seed, step_dev=self.step_dev)
         if self.distributed:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            D.allreduce_gradients(self.grad, self.pg)
         if self.grad_clip > 0:
             N.sumsq(self.grad, self.sumsq, step_inc=self.step_dev)
         else:

@@ -1,0 +1,81 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel host logic: shard ranges, the count-weighted
+gradient reduction for ragged shards, and the post-reduce clip norm."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_rows, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "st-dadk_amd"))
+    from stnf import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)                      # same data on every rank, each takes its shard
+        X = torch.randn(n_rows, 7, dtype=torch.float64)
+        y = torch.randn(n_rows, 1, dtype=torch.float64)
+        w = torch.randn(7, 1, dtype=torch.float64)
+        lo, hi = D.shard_range(n_rows, rank, world)
+        G = D.global_rows(hi - lo)
+        assert G == n_rows
+        scale = D.grad_scale(G, 1)
+        # local gradient of scale * sum((Xw - y)^2) — what stdadk_train_fwd_bwd_f32 produces per rank
+        r = X[lo:hi] @ w - y[lo:hi]
+        g_local = (2.0 * scale) * (X[lo:hi].T @ r)
+        flat = g_local.reshape(-1).clone()
+        D.allreduce_gradients(flat)
+        # reference: gradient of the global-batch MEAN squared error
+        g_ref = (2.0 / n_rows) * (X.T @ (X @ w - y))
+        assert torch.allclose(flat.view_as(g_ref), g_ref, rtol=1e-12, atol=1e-14)
+        coef = D.clip_coefficient(flat, 0.05)
+        ref = min(1.0, 0.05 / (float(g_ref.norm()) + 1e-6))
+        assert abs(coef - ref) < 1e-12
+        q.put((rank, lo, hi, float(flat.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [64, 101])          # 101 => ragged shards (51 / 50)
+def test_count_weighted_allreduce_gloo(n_rows):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n_rows
+    assert abs(res[0][3] - res[1][3]) < 1e-12          # every rank holds the same reduced gradient
+
+
+def test_shard_range_covers_everything():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "st-dadk_amd"))
+    from stnf.distributed import shard_range
+    for n in (0, 1, 7, 8, 100_000, 1_000_003):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
