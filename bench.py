@@ -176,9 +176,10 @@ def main():
         return coords[idx], t[idx], y[idx]
 
     def run(k0, k):
+        # the observation shard stays resident in HBM; a step takes the index slice of its batch
         for i in range(k0, k0 + k):
-            c, tt, yy = batch(i)
-            eng.step(None, c, tt, yy, global_rows=B * world)
+            j = i % batches_per_epoch
+            eng.step_indexed(coords, t, y, perm[j * B:j * B + B], global_rows=B * world)
 
     run(0, args.warmup)
     torch.cuda.synchronize()

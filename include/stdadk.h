@@ -213,6 +213,13 @@ int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *basis, const stdadk_mlp_de
                              void *workspace, size_t workspace_bytes, uint64_t drop_seed,
                              const int32_t *step_dev, int32_t flags, stdadk_stream_t stream);
 
+/* A0  batch producer (scripts/train_st_interp.py:413-460 dataset + collate, :609-612 H2D): rows
+ * idx[b] (int64) of the device-resident observation arrays into contiguous batch buffers, one launch.
+ * coords [N,2], t [N], y [N,Q], X [N,p] (NULL when p == 0). */
+int stdadk_gather_batch_f32(const float *coords, const float *t, const float *y, const float *X,
+                            const int64_t *idx, int64_t B, int32_t Q, int32_t p, float *coords_out,
+                            float *t_out, float *y_out, float *X_out, stdadk_stream_t stream);
+
 /* Integer bookkeeping of the window path, exposed for bit-exact tests:
  *   stdadk_bin_obs_f32: cell key of every observation (cx*G+cy, cx = clamp(floor(x*G),0,G-1)),
  *     cell_start[G*G+1] (first sorted position of every cell) and perm[B] (sorted position ->

@@ -24,7 +24,31 @@ struct GemmArgs {
   int kps;            // K per split, multiple of 32 (ignored when splits == 1)
   float *slab;        // splits * slab_stride floats when splits > 1
   int64_t slab_stride;
+  int always_slab = 0;  // write the (single) partial to the slab even when splits == 1
 };
+
+// a table of TN products for one launch (gemm_tn_grouped_kernel) and of partial-sum reductions
+constexpr int GEMM_GROUP_MAX = 8;
+struct GemmGroup {
+  int n = 0;
+  GemmArgs job[GEMM_GROUP_MAX];
+  int first_block[GEMM_GROUP_MAX + 1];
+};
+struct ReduceJob {
+  const float *src;   // src[s*stride + i]
+  float *dst;         // dst[i] = sum_s
+  int n, splits;
+  int64_t stride;
+};
+constexpr int REDUCE_GROUP_MAX = 40;
+struct ReduceGroup {
+  int n = 0;
+  ReduceJob job[REDUCE_GROUP_MAX];
+  int first_block[REDUCE_GROUP_MAX + 1];
+};
+int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st);     // every job: a_km = b_km = true, aligned
+int launch_reduce_jobs(ReduceGroup &grp, hipStream_t st);
+bool gemm_tn_groupable(const float *A, int64_t lda, const float *B, int64_t ldb);
 
 // Picks a split count so the launch has >= ~256 workgroups; returns splits and sets kps.
 int gemm_pick_splits(int M, int N, int K, int *kps, bool big_tile);

@@ -138,19 +138,18 @@ __device__ __forceinline__ void read_frag(const float *lds, int row, int s, int 
 }
 
 template <int BM, int BN, bool A_KM, bool B_KM, int VA, int VB>
-__global__ __launch_bounds__(GT) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by, int bz, float *lds) {
   constexpr int TM = BM / 64, TN = BN / 64;
   using GA = TileGeom<BM, A_KM>;
   using GB = TileGeom<BN, B_KM>;
-  __shared__ __attribute__((aligned(16))) float lds[GA::SIZE + GB::SIZE];
   float *As = lds, *Bs = lds + GA::SIZE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
   int kbeg = 0, kend = g.K;
   if (g.splits > 1) {
-    kbeg = blockIdx.z * g.kps;
+    kbeg = bz * g.kps;
     kend = min(g.K, kbeg + g.kps);
   }
 
@@ -196,8 +195,8 @@ __global__ __launch_bounds__(GT) void gemm_f32_kernel(GemmArgs g) {
   // epilogue: acc reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile
   float *Cbase;
   int64_t ldc;
-  if (g.splits > 1) {
-    Cbase = g.slab + (int64_t)blockIdx.z * g.slab_stride;
+  if (g.splits > 1 || g.always_slab) {
+    Cbase = g.slab + (int64_t)bz * g.slab_stride;
     ldc = g.N;
   } else {
     Cbase = g.C;
@@ -210,13 +209,92 @@ __global__ __launch_bounds__(GT) void gemm_f32_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j) {
       int col = n0 + wn + j * 32 + cl;
       if (col >= g.N) continue;
-      float bv = (g.splits == 1 && g.bias) ? g.bias[col] : 0.f;
+      float bv = (g.splits == 1 && !g.always_slab && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < g.M) Cbase[(int64_t)row * ldc + col] = acc[i][j][r] + bv;
       }
     }
+}
+
+template <int BM, int BN, bool A_KM, bool B_KM, int VA, int VB>
+__global__ __launch_bounds__(GT) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[TileGeom<BM, A_KM>::SIZE + TileGeom<BN, B_KM>::SIZE];
+  gemm_tile_body<BM, BN, A_KM, B_KM, VA, VB>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+// Several independent C_j = A_j^T B_j products (reduction over the batch) in ONE launch: block ->
+// (job, tile, split) through a prefix table; every job writes split-K slabs.
+__global__ __launch_bounds__(GT) void gemm_tn_grouped_kernel(GemmGroup grp) {
+  __shared__ __attribute__((aligned(16))) float lds[TileGeom<64, true>::SIZE * 2];
+  int j = 0;
+  while (j + 1 < grp.n && (int)blockIdx.x >= grp.first_block[j + 1]) ++j;
+  const GemmArgs &g = grp.job[j];
+  int b = blockIdx.x - grp.first_block[j];
+  const int tn = (g.N + 63) >> 6, tm = (g.M + 63) >> 6;
+  const int bz = b / (tn * tm);
+  b -= bz * tn * tm;
+  gemm_tile_body<64, 64, true, true, 4, 4>(g, b % tn, b / tn, bz, lds);
+}
+
+// dst_j[i] = sum_s src_j[s*stride_j + i], i < n_j, for a table of jobs (split-K slabs, per-workgroup
+// column partials): 64 columns x 16 s-groups per workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void reduce_jobs_kernel(ReduceGroup grp) {
+  __shared__ float red[16][64];
+  int j = 0;
+  while (j + 1 < grp.n && (int)blockIdx.x >= grp.first_block[j + 1]) ++j;
+  const ReduceJob &jb = grp.job[j];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = (blockIdx.x - grp.first_block[j]) * 64 + tx;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < jb.n) {
+    int s = ty;
+    for (; s + 16 < jb.splits; s += 32) {
+      s0 += jb.src[(int64_t)s * jb.stride + c];
+      s1 += jb.src[(int64_t)(s + 16) * jb.stride + c];
+    }
+    for (; s < jb.splits; s += 16) s0 += jb.src[(int64_t)s * jb.stride + c];
+  }
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty == 0 && c < jb.n) {
+    float v = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 16; ++gq) v += red[gq][tx];
+    jb.dst[c] = v;
+  }
+}
+
+int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st) {
+  int nb = 0;
+  for (int j = 0; j < grp.n; ++j) {
+    GemmArgs &g = grp.job[j];
+    STDADK_REQUIRE(g.slab && g.kps % BK == 0 && g.splits >= 1, STDADK_E_ARG, "grouped gemm: bad job %d", j);
+    g.always_slab = 1;
+    grp.first_block[j] = nb;
+    nb += (int)(ceil_div(g.M, 64) * ceil_div(g.N, 64)) * g.splits;
+  }
+  if (nb == 0) return 0;
+  STDADK_LAUNCH(gemm_tn_grouped_kernel, dim3((unsigned)nb), dim3(GT), 0, st, grp);
+  STDADK_CHECK_LAUNCH("gemm_tn_grouped");
+  return 0;
+}
+
+int launch_reduce_jobs(ReduceGroup &grp, hipStream_t st) {
+  int nb = 0;
+  for (int j = 0; j < grp.n; ++j) {
+    grp.first_block[j] = nb;
+    nb += (int)ceil_div(grp.job[j].n, 64);
+  }
+  if (nb == 0) return 0;
+  STDADK_LAUNCH(reduce_jobs_kernel, dim3((unsigned)nb), dim3(1024), 0, st, grp);
+  STDADK_CHECK_LAUNCH("reduce_jobs");
+  return 0;
+}
+
+bool gemm_tn_groupable(const float *A, int64_t lda, const float *B, int64_t ldb) {
+  return ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0;
 }
 
 static int vec_of(const float *p, int64_t ld) {

@@ -86,6 +86,21 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
     size_t s = gemm_slab_floats(Kt, d->hidden[0], (int)B); slab = s > slab ? s : slab;
     if (p_cov > 0) { s = gemm_slab_floats(p_cov, d->hidden[0], (int)B); slab = s > slab ? s : slab; }
   }
+  {
+    // the grouped dW launch of the fused-tail backward keeps every job's slabs alive at once
+    auto job_floats = [&](int M, int N) {
+      int kps;
+      int sp = gemm_pick_splits(M, N, (int)B, &kps, false);
+      return (size_t)sp * M * N;
+    };
+    size_t grouped = 0;
+    for (int l = 1; l < d->n_hidden; ++l) grouped += job_floats(d->hidden[l], d->hidden[l - 1]);
+    if (mode == PLAN_STEP_WINDOW && d->n_hidden > 0) {
+      grouped += job_floats(Kt, d->hidden[0]);
+      if (p_cov > 0) grouped += job_floats(p_cov, d->hidden[0]);
+    }
+    slab = grouped > slab ? grouped : slab;
+  }
   p->slab_floats = slab;
   p->slab = take(slab);
   p->dA = take((size_t)B * hmax);
@@ -455,6 +470,10 @@ struct Ctx {
   float *mse_loss = nullptr;
   bool mse_done = false;        // set by run_forward when the loss was fused into the tail kernel
   const float *dz0 = nullptr;   // set by run_backward: dZ of layer 0
+  // extra products C[M][H0] = A^T dZ_0 (reduction over the batch) to run with the dW GEMMs of the
+  // fused-tail backward: the temporal / covariate rows of dW0^T on the window path
+  int n_extra = 0;
+  struct { const float *A; int64_t lda; int M; float *C; } extra[2];
 };
 
 static bool tail_enabled() {
@@ -606,34 +625,60 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     rc = tail_backward(a, st);
     if (rc) return rc;
     c.dz0 = ws + pl.dZl[0];
-    {
-      int n = Q * (hL + 1);
-      STDADK_LAUNCH(head_reduce_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64 * CS_G), 0, st, part, nb16, Q, hL,
-                    G->W[L], G->b[L]);
-      STDADK_CHECK_LAUNCH("head_reduce");
-    }
+    // ---- ONE grouped launch for the dW products, ONE grouped launch for every fixed-order sum
+    GemmGroup gg;
+    ReduceGroup rg;
+    size_t slab_off = 0;
+    auto add_reduce = [&](const float *src, float *dst, int n, int splits, int64_t stride) -> bool {
+      if (rg.n >= REDUCE_GROUP_MAX) return false;
+      ReduceJob &j = rg.job[rg.n++];
+      j.src = src; j.dst = dst; j.n = n; j.splits = splits; j.stride = stride;
+      return true;
+    };
+    // C[M][N] (contiguous) = A^T Bm, both operands stored [B rows][.]; falls back to a stand-alone GEMM
+    auto add_tn = [&](const float *A, int64_t lda, const float *Bm, int64_t ldb, int M, int N, float *C) -> int {
+      if (gg.n < GEMM_GROUP_MAX && rg.n < REDUCE_GROUP_MAX && gemm_tn_groupable(A, lda, Bm, ldb)) {
+        GemmArgs &g = gg.job[gg.n++];
+        g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = N; g.bias = nullptr;
+        g.M = M; g.N = N; g.K = (int)B;
+        g.splits = gemm_pick_splits(M, N, (int)B, &g.kps, false);
+        g.slab = slab + slab_off; g.slab_stride = (int64_t)M * N;
+        slab_off += (size_t)g.splits * M * N;
+        add_reduce(g.slab, C, M * N, g.splits, g.slab_stride);
+        return 0;
+      }
+      return gemm_run(A, lda, true, Bm, ldb, true, M, N, (int)B, nullptr, C, N, slab + slab_off, false, nullptr, st);
+    };
+    add_reduce(part, G->W[L], Q * hL, (int)nb16, (int64_t)Q * (hL + 1));
+    add_reduce(part + Q * hL, G->b[L], Q, (int)nb16, (int64_t)Q * (hL + 1));
     for (int l = L - 1; l >= 0; --l) {
       const int h = d->hidden[l];
-      ColsumOut co;
+      const float *pp = ws + pl.partl[l];
       if (d->layernorm) {
-        co.o[0] = G->ln_g[l]; co.o[1] = G->ln_b[l]; co.o[2] = G->b[l];
-        STDADK_LAUNCH(colsum_kernel, dim3((unsigned)ceil_div(3 * h, 64)), dim3(64 * CS_G), 0, st, ws + pl.partl[l],
-                      nb16, (int64_t)3 * h, h, 3, co);
-      } else {
-        co.o[0] = G->b[l]; co.o[1] = co.o[2] = nullptr;
-        STDADK_LAUNCH(colsum_kernel, dim3((unsigned)ceil_div(h, 64)), dim3(64 * CS_G), 0, st,
-                      ws + pl.partl[l] + 2 * h, nb16, (int64_t)3 * h, h, 1, co);
+        add_reduce(pp, G->ln_g[l], h, (int)nb16, (int64_t)3 * h);
+        add_reduce(pp + h, G->ln_b[l], h, (int)nb16, (int64_t)3 * h);
       }
-      STDADK_CHECK_LAUNCH("colsum");
-      if (l == 0 && !layer0_dense) break;
-      const float *ain = l > 0 ? ws + pl.act[l - 1] : features;
-      const int64_t ldin = l > 0 ? d->hidden[l - 1] : ldf;
-      const int kin = l > 0 ? d->hidden[l - 1] : d->in_dim;
-      const float *dZl = ws + pl.dZl[l];
-      if (l == 0 && c.w0t)
-        rc = gemm_run(ain, ldin, true, dZl, h, true, kin, h, (int)B, nullptr, G->W[l], h, slab, false, nullptr, st);
+      add_reduce(pp + 2 * h, G->b[l], h, (int)nb16, (int64_t)3 * h);
+      if (l == 0) break;
+      // dW_l[h][kin] = dZ_l^T act_{l-1}
+      rc = add_tn(ws + pl.dZl[l], h, ws + pl.act[l - 1], d->hidden[l - 1], h, d->hidden[l - 1], G->W[l]);
+      if (rc) return rc;
+    }
+    for (int e = 0; e < c.n_extra; ++e) {
+      rc = add_tn(c.extra[e].A, c.extra[e].lda, c.dz0, d->hidden[0], c.extra[e].M, d->hidden[0], c.extra[e].C);
+      if (rc) return rc;
+    }
+    c.n_extra = 0;     // consumed
+    rc = launch_gemm_tn_grouped(gg, st);
+    if (rc) return rc;
+    rc = launch_reduce_jobs(rg, st);
+    if (rc) return rc;
+    if (layer0_dense) {
+      const int h = d->hidden[0];
+      if (c.w0t)
+        rc = gemm_run(features, ldf, true, c.dz0, h, true, d->in_dim, h, (int)B, nullptr, G->W[0], h, slab, false, nullptr, st);
       else
-        rc = gemm_run(dZl, h, true, ain, ldin, true, h, kin, (int)B, nullptr, G->W[l], kin, slab, false, nullptr, st);
+        rc = gemm_run(c.dz0, h, true, features, ldf, true, h, d->in_dim, (int)B, nullptr, G->W[0], d->in_dim, slab, false, nullptr, st);
       if (rc) return rc;
     }
     return 0;
@@ -920,27 +965,34 @@ static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const 
                        (const int *)(ws + c.pl.perm), (int)c.B, Q, ws + c.pl.dY);
     STDADK_CHECK_LAUNCH("gather_rows");
   }
+  // dW0^T rows of the temporal / covariate columns: small products that ride along with the dW
+  // GEMMs of the fused-tail backward (or run on their own on the generic path)
+  c.n_extra = 0;
+  c.extra[c.n_extra].A = ws + c.pl.psi; c.extra[c.n_extra].lda = c.pl.ld_psi; c.extra[c.n_extra].M = (int)b->Kt;
+  c.extra[c.n_extra].C = c.G->W[0] + (size_t)(b->p + b->Ks) * H;
+  ++c.n_extra;
+  if (b->p > 0) {
+    c.extra[c.n_extra].A = ws + c.pl.X_s; c.extra[c.n_extra].lda = b->p; c.extra[c.n_extra].M = b->p;
+    c.extra[c.n_extra].C = c.G->W[0];
+    ++c.n_extra;
+  }
+  STDADK_REQUIRE(c.G->W[0], STDADK_E_ARG, "backward: dW[0] NULL");
   rc = run_backward(c, ws + c.pl.dY, nullptr, 0, false);
   if (rc) return rc;
-  // dW0^T: spatial rows by the knot-block owners, temporal / covariate rows by small GEMMs
-  STDADK_REQUIRE(c.G->W[0], STDADK_E_ARG, "backward: dW[0] NULL");
+  for (int e = 0; e < c.n_extra; ++e) {     // not consumed by a grouped launch
+    rc = gemm_run(c.extra[e].A, c.extra[e].lda, true, c.dz0, H, true, c.extra[e].M, H, (int)c.B, nullptr,
+                  c.extra[e].C, H, ws + c.pl.slab, false, nullptr, c.st);
+    if (rc) return rc;
+  }
+  c.n_extra = 0;
+  // dW0^T spatial rows: every knot row by the wave that owns it
   L1BwdArgs a;
   a.g = make_grid(b);
   a.xs = ws + c.pl.xs; a.ys = ws + c.pl.ys;
   a.cell_start = (const int *)(ws + c.pl.cell_start);
   a.G = c.pl.G; a.B = (int)c.B; a.H = H;
   a.dZ = c.dz0; a.dW0T = c.G->W[0];
-  rc = l1_window_backward(a, b->basis, c.st);
-  if (rc) return rc;
-  rc = gemm_run(ws + c.pl.psi, c.pl.ld_psi, true, c.dz0, H, true, (int)b->Kt, H, (int)c.B, nullptr,
-                c.G->W[0] + (size_t)(b->p + b->Ks) * H, H, ws + c.pl.slab, false, nullptr, c.st);
-  if (rc) return rc;
-  if (b->p > 0) {
-    rc = gemm_run(ws + c.pl.X_s, b->p, true, c.dz0, H, true, b->p, H, (int)c.B, nullptr, c.G->W[0], H,
-                  ws + c.pl.slab, false, nullptr, c.st);
-    if (rc) return rc;
-  }
-  return 0;
+  return l1_window_backward(a, b->basis, c.st);
 }
 
 extern "C" int stdadk_forward_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,

@@ -52,7 +52,7 @@ struct TailBwdArgs {
   int Q;
   const float *dY;              // [B][Q]
   const float *act_last;        // [B][h_last] activations feeding the output layer
-  float *part_head;             // [nblk][Q][h_last+1] partials of dWo (last column: dbo)
+  float *part_head;             // [nblk][Q*h_last | Q] partials of dWo then dbo
   float *WT[TAIL_MAX_LAYERS];   // [hp_l][h_l] scratch: W_l transposed (filled by tail_backward), l >= 1
   float *dZ[TAIL_MAX_LAYERS];   // [B][h_l] out: gradient w.r.t. the pre-LayerNorm output of layer l
   float *part[TAIL_MAX_LAYERS]; // [nblk][3][h_l] column partials (dgamma, dbeta, db) per workgroup

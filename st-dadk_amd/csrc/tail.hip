@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
     for (int qq = 0; qq < a.Q; ++qq) d = fmaf(sdy[row * a.Q + qq], a.Wo[qq * hl + col], d);
     d0[row * ACT_LD + col] = d;
   }
-  // output-layer weight gradient partials of this tile: part_head[blk][qq][hl+1] (last column = db)
+  // output-layer weight gradient partials of this tile: part_head[blk][Q*hl (dWo) | Q (dbo)]
   {
     float *ph = a.part_head + (size_t)blockIdx.x * a.Q * (hl + 1);
     const int nrow = min(R, a.B - row0);
@@ -293,12 +293,12 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
       }
 #pragma unroll
       for (int qq = 0; qq < TAIL_MAXQ; ++qq)
-        if (qq < a.Q) ph[qq * (hl + 1) + col] = pw[qq];
+        if (qq < a.Q) ph[qq * hl + col] = pw[qq];
     }
     if (tid < a.Q) {
       float sb = 0.f;
       for (int row = 0; row < nrow; ++row) sb += sdy[row * a.Q + tid];
-      ph[tid * (hl + 1) + hl] = sb;
+      ph[a.Q * hl + tid] = sb;
     }
   }
   __syncthreads();

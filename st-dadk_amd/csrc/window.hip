@@ -110,9 +110,90 @@ __global__ void zero_ints_kernel(int *__restrict__ p, int n) {
   if (i < n) p[i] = 0;
 }
 
+// Whole binning in ONE workgroup for small batches (B <= SMALL_B, G <= SMALL_G): histogram, scan,
+// scatter and in-cell ordering with the counters and the unordered permutation in LDS.  Same
+// outputs, bit for bit, as the multi-kernel path.
+constexpr int SMALL_B = 8192, SMALL_G = 64;
+__global__ __launch_bounds__(1024) void bin_small_kernel(const float *__restrict__ coords,
+                                                         const float *__restrict__ t,
+                                                         const float *__restrict__ y, int Q,
+                                                         const float *__restrict__ X, int p, int B, int G,
+                                                         int *__restrict__ keys, int *__restrict__ cell_start,
+                                                         int *__restrict__ perm, float *__restrict__ xs,
+                                                         float *__restrict__ ys, float *__restrict__ ts,
+                                                         float *__restrict__ y_s, float *__restrict__ X_s) {
+  __shared__ int hist[SMALL_G * SMALL_G];      // counts, then running cursors
+  __shared__ int start[SMALL_G * SMALL_G + 1];
+  __shared__ int ptmp[SMALL_B];
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int ncell = G * G;
+  for (int c = tid; c < ncell; c += 1024) hist[c] = 0;
+  __syncthreads();
+  for (int b = tid; b < B; b += 1024) {
+    const int c = cell_of(coords[2 * b], coords[2 * b + 1], G);
+    keys[b] = c;
+    atomicAdd(&hist[c], 1);
+  }
+  __syncthreads();
+  // exclusive scan: thread tid owns cells [tid*per, tid*per+per)
+  const int per = (ncell + 1023) / 1024;
+  const int i0 = tid * per, i1 = min(i0 + per, ncell);
+  int s = 0;
+  for (int i = i0; i < i1; ++i) s += hist[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - s;
+  for (int i = i0; i < i1; ++i) {
+    const int cnt = hist[i];
+    start[i] = run;
+    cell_start[i] = run;
+    hist[i] = run;            // cursor for the scatter
+    run += cnt;
+  }
+  if (tid == 1023) { start[ncell] = part[1023]; cell_start[ncell] = part[1023]; }
+  __syncthreads();
+  for (int b = tid; b < B; b += 1024) {
+    const int pos = atomicAdd(&hist[keys[b]], 1);
+    ptmp[pos] = b;
+  }
+  __syncthreads();
+  // order every cell by original index (rank by counting) and emit the sorted arrays
+  for (int c = tid; c < ncell; c += 1024) {
+    const int s0 = start[c], s1 = start[c + 1];
+    for (int i = s0; i < s1; ++i) {
+      const int b = ptmp[i];
+      int rank = 0;
+      for (int j = s0; j < s1; ++j) rank += ptmp[j] < b;
+      const int pos = s0 + rank;
+      perm[pos] = b;
+      xs[pos] = coords[2 * b];
+      ys[pos] = coords[2 * b + 1];
+      if (t) ts[pos] = t[b];
+      if (y_s)
+        for (int q = 0; q < Q; ++q) y_s[(int64_t)pos * Q + q] = y[(int64_t)b * Q + q];
+      if (X_s)
+        for (int q = 0; q < p; ++q) X_s[(int64_t)pos * p + q] = X[(int64_t)b * p + q];
+    }
+  }
+}
+
 int bin_obs(const float *coords, const float *t, const float *y, int Q, const float *X, int p, int B,
             int G, const BinBuffers &bb, hipStream_t st) {
   const int ncell = G * G;
+  if (B <= SMALL_B && G <= SMALL_G) {
+    STDADK_LAUNCH(bin_small_kernel, dim3(1), dim3(1024), 0, st, coords, t, y, Q, X, p, B, G, bb.keys,
+                  bb.cell_start, bb.perm, bb.xs, bb.ys, bb.ts, y ? bb.y_s : (float *)nullptr,
+                  (X && p > 0) ? bb.X_s : (float *)nullptr);
+    STDADK_CHECK_LAUNCH("bin_obs");
+    return 0;
+  }
   // a kernel, not hipMemsetAsync: the step must stay a pure chain of kernel nodes under capture
   STDADK_LAUNCH(zero_ints_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st, bb.hist, ncell);
   const unsigned nb = (unsigned)ceil_div(B, 256);
@@ -120,10 +201,27 @@ int bin_obs(const float *coords, const float *t, const float *y, int Q, const fl
   STDADK_LAUNCH(cell_scan_kernel, dim3(1), dim3(1024), 0, st, bb.hist, ncell, bb.cell_start, bb.cursor);
   STDADK_LAUNCH(cell_scatter_kernel, dim3(nb), dim3(256), 0, st, bb.keys, B, bb.cursor, bb.perm_tmp);
   STDADK_LAUNCH(cell_order_kernel, dim3((unsigned)ceil_div(ncell, 128)), dim3(128), 0, st, bb.cell_start,
-                     ncell, bb.perm_tmp, bb.perm, coords, t, y, Q, X, p, bb.xs, bb.ys, bb.ts,
-                     y ? bb.y_s : (float *)nullptr, (X && p > 0) ? bb.X_s : (float *)nullptr);
+                ncell, bb.perm_tmp, bb.perm, coords, t, y, Q, X, p, bb.xs, bb.ys, bb.ts,
+                y ? bb.y_s : (float *)nullptr, (X && p > 0) ? bb.X_s : (float *)nullptr);
   STDADK_CHECK_LAUNCH("bin_obs");
   return 0;
+}
+
+// One launch instead of a handful of framework gathers: rows idx[b] of the resident observation
+// arrays into contiguous batch buffers (the batch producer of train_st_interp.py:413-460,609-612).
+__global__ void gather_batch_kernel(const float *__restrict__ coords, const float *__restrict__ t,
+                                    const float *__restrict__ y, const float *__restrict__ X,
+                                    const int64_t *__restrict__ idx, int B, int Q, int p,
+                                    float *__restrict__ coords_o, float *__restrict__ t_o,
+                                    float *__restrict__ y_o, float *__restrict__ X_o) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int64_t r = idx[b];
+  coords_o[2 * b] = coords[2 * r];
+  coords_o[2 * b + 1] = coords[2 * r + 1];
+  t_o[b] = t[r];
+  for (int q = 0; q < Q; ++q) y_o[(int64_t)b * Q + q] = y[r * Q + q];
+  for (int q = 0; q < p; ++q) X_o[(int64_t)b * p + q] = X[r * p + q];
 }
 
 __global__ void unpermute_kernel(const float *__restrict__ in, const int *__restrict__ perm, int B, int Q,
@@ -505,6 +603,19 @@ extern "C" int stdadk_knot_windows_i32(const float *coords, int64_t B, const int
   STDADK_LAUNCH(knot_windows_kernel, dim3((unsigned)ceil_div(B * n_levels, 256)), dim3(256), 0,
                      (hipStream_t)stream, coords, (int)B, (int)n_levels, lt, p, ix0, iy0, col0);
   STDADK_CHECK_LAUNCH("knot_windows");
+  return 0;
+}
+
+extern "C" int stdadk_gather_batch_f32(const float *coords, const float *t, const float *y, const float *X,
+                                       const int64_t *idx, int64_t B, int32_t Q, int32_t p, float *coords_out,
+                                       float *t_out, float *y_out, float *X_out, stdadk_stream_t stream) {
+  STDADK_REQUIRE(B >= 0 && B < (1ll << 31) && Q >= 0 && p >= 0, STDADK_E_ARG, "gather_batch: bad sizes");
+  if (B == 0) return 0;
+  STDADK_REQUIRE(coords && t && idx && coords_out && t_out && (Q == 0 || (y && y_out)) && (p == 0 || (X && X_out)),
+                 STDADK_E_ARG, "gather_batch: NULL pointer");
+  STDADK_LAUNCH(gather_batch_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, (hipStream_t)stream, coords, t, y,
+                X, idx, (int)B, Q, p, coords_out, t_out, y_out, X_out);
+  STDADK_CHECK_LAUNCH("gather_batch");
   return 0;
 }
 

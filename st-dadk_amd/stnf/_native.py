@@ -75,6 +75,9 @@ _SIGNATURES = {
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
                                            C.c_void_p, C.c_int32, C.c_void_p]),
+    "stdadk_gather_batch_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "stdadk_bin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "stdadk_bin_obs_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -293,6 +296,20 @@ def train_fwd_bwd(basis, desc, params, grads, coords, t, X, y, B, grad_scale, lo
                                         workspace.numel() * workspace.element_size(), seed,
                                         _dev(step_dev, "step_dev"), flags, _stream())
     _check(rc, "stdadk_train_fwd_bwd_f32")
+
+
+def gather_batch(coords, t, y, X, idx, coords_out, t_out, y_out, X_out):
+    """Rows idx (int64 device tensor) of the resident observation arrays -> contiguous batch buffers."""
+    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+        raise RuntimeError("gather_batch: idx must be a contiguous int64 tensor on the device")
+    B = idx.numel()
+    Q = y.shape[1] if y is not None else 0
+    p = X.shape[1] if X is not None else 0
+    rc = lib().stdadk_gather_batch_f32(_dev(coords, "coords"), _dev(t, "t"), _dev(y, "y"), _dev(X, "X"),
+                                       idx.data_ptr(), B, Q, p, _dev(coords_out, "coords_out"),
+                                       _dev(t_out, "t_out"), _dev(y_out, "y_out"), _dev(X_out, "X_out"),
+                                       _stream())
+    _check(rc, "stdadk_gather_batch_f32")
 
 
 def bin_obs(coords, G):

@@ -105,6 +105,8 @@ class TrainStep:
         self._g_in = None
         self._g_B = None
         self._warm = False
+        self._ix = None
+        self._ix_graph = None
 
     # ------------------------------------------------------------------------------------
     def set_lr(self, lr):
@@ -148,6 +150,51 @@ class TrainStep:
             self._step_graph(X, coords, t, y, B, global_rows)
         else:
             self._enqueue(X, coords, t, y, B, global_rows)
+        self.step_count += 1
+        self.rows_seen += B
+
+    def step_indexed(self, coords_all, t_all, y_all, idx, X_all=None, global_rows=None):
+        """One optimisation step on rows `idx` (int64 device tensor) of device-RESIDENT observation
+        arrays coords_all (N,2), t_all (N,) or (N,1), y_all (N,Q), X_all (N,p)|None.  The batch is
+        gathered by one library kernel into static buffers (the reference builds it from a Python
+        list of dicts, torch.stack and four H2D copies per step: train_st_interp.py:413-460,609-612);
+        with use_graph the gather is part of the captured graph."""
+        B = idx.numel()
+        if B > self.max_batch:
+            raise RuntimeError(f"batch {B} > max_batch {self.max_batch}")
+        if global_rows is None:
+            global_rows = B * self.world
+        p, Q = self.model.p, self.model.output_dim
+        if self._ix is None or self._ix[0].numel() != B:
+            self._ix = (torch.empty(B, dtype=torch.int64, device=self.dev),
+                        torch.empty(B, 2, device=self.dev), torch.empty(B, device=self.dev),
+                        torch.empty(B, Q, device=self.dev),
+                        torch.empty(B, p, device=self.dev) if p > 0 else None)
+            self._ix_graph = None
+        ib, cb, tb, yb, xb = self._ix
+        t_all = t_all.view(-1)
+        Xa = X_all if p > 0 else None
+
+        def enqueue():
+            N.gather_batch(coords_all, t_all, y_all, Xa, ib, cb, tb, yb, xb)
+            self._enqueue(xb, cb, tb, yb, B, global_rows)
+
+        ib.copy_(idx)
+        if self.use_graph and not self.distributed:
+            if not self._warm:
+                self._warm = True
+                enqueue()
+            else:
+                key = (B, global_rows, coords_all.data_ptr(), t_all.data_ptr(), y_all.data_ptr())
+                if self._ix_graph is None or self._ix_graph[0] != key:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        enqueue()
+                    self._ix_graph = (key, g)
+                self._ix_graph[1].replay()
+        else:
+            enqueue()
         self.step_count += 1
         self.rows_seen += B
 

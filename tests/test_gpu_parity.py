@@ -542,3 +542,34 @@ def test_predictor_matches_module_forward():
         pr = Predictor(m, chunk=2048, use_graph=True, force_dense=dense)
         out = pr.predict(coords, t)
         assert torch.allclose(out, ref, rtol=1e-5, atol=2e-6)
+
+
+def test_step_indexed_equals_step():
+    """The library's batch gather (A0) + step == step on torch-indexed tensors, eager and graph."""
+    from stnf.engine import TrainStep
+    from stnf import _native as N
+    cfg = cases.MODEL_CASES["default227"]
+    d = dev()
+    rs = np.random.RandomState(8)
+    n = 1000
+    coords = torch.from_numpy(rs.uniform(0, 1, (n, 2)).astype(np.float32)).to(d)
+    t = torch.from_numpy(rs.uniform(0, 1, (n, 1)).astype(np.float32)).to(d)
+    y = torch.from_numpy(rs.standard_normal((n, 1)).astype(np.float32)).to(d)
+    idx = torch.from_numpy(rs.permutation(n)[:193].astype(np.int64)).to(d)
+    # the gather itself is exact
+    co, to, yo = torch.empty(193, 2, device=d), torch.empty(193, device=d), torch.empty(193, 1, device=d)
+    N.gather_batch(coords, t.view(-1), y, None, idx, co, to, yo, None)
+    assert torch.equal(co, coords[idx]) and torch.equal(to, t.view(-1)[idx]) and torch.equal(yo, y[idx])
+    res = []
+    for mode in ("plain", "indexed", "indexed_graph"):
+        m = build_model(cfg)
+        eng = TrainStep(m, ema_decay=0.99, max_batch=193, use_graph=(mode == "indexed_graph"))
+        for _ in range(3):
+            if mode == "plain":
+                eng.step(None, coords[idx], t[idx], y[idx])
+            else:
+                eng.step_indexed(coords, t, y, idx)
+        res.append((eng.mean_loss(), eng.flat.clone()))
+    for other in res[1:]:
+        assert abs(res[0][0] - other[0]) <= 1e-6 * abs(res[0][0])
+        assert torch.allclose(res[0][1], other[1], rtol=1e-5, atol=1e-6)
