@@ -108,7 +108,7 @@ def cpu_baseline(wl, batch, dropout, budget_s=20.0):
                        f"same model/config/optimizer, {el:.1f} s of CPU work, {cores} torch threads)")
 
 
-def kernel_work(name, B, D, H, P_flat, nnz_pairs, Kt):
+def kernel_work(name, B, D, H, P_flat, nnz_pairs, Kt, Q=1):
     """Algorithmic work of one launch of a library kernel: (bound, amount, unit) or None.
     HBM kernels are priced in bytes that MUST cross HBM, MFMA kernels in flops of the mathematical
     product (DESIGN.md 'kernels')."""
@@ -122,6 +122,14 @@ def kernel_work(name, B, D, H, P_flat, nnz_pairs, Kt):
         return "mfma", 2.0 * nnz_pairs * H[0], "flop"    # dW0^T rows: one fma per non-zero (obs,knot) x H
     if "l1_window_fwd_kernel" in name:
         return "mfma", 2.0 * (nnz_pairs + B * Kt) * H[0], "flop"
+    if "tail_fwd_kernel" in name or "tail_bwd_kernel" in name:
+        # Linear layers after the first (+ output layer): forward z = a W^T, backward dA = dZ W
+        fl = sum(2.0 * B * H[i] * H[i - 1] for i in range(1, len(H))) + 2.0 * B * H[-1] * Q
+        return "mfma", fl, "flop"
+    if "gemm_tn_grouped_kernel" in name:
+        # dW_l = dZ_l^T a_{l-1} for l >= 1, plus the temporal rows of dW0^T
+        fl = sum(2.0 * B * H[i] * H[i - 1] for i in range(1, len(H))) + 2.0 * B * Kt * H[0]
+        return "mfma", fl, "flop"
     if name.startswith("gemm_f32_kernel") and "M=" in name:
         f = dict(kv.split("=") for kv in name.split() if "=" in kv)
         return "mfma", 2.0 * int(f["M"]) * int(f["N"]) * int(f["K"]), "flop"
@@ -199,17 +207,21 @@ def main():
         el = tmax.item()
     loss = eng.mean_loss()
 
+    # ---- per-kernel device time of the step, live, with HIP events on the launch stream.  Every
+    # rank runs these steps (they contain the gradient all-reduce); rank 0 reports.
+    D = model.input_dim
+    H = wl["hidden_dims"]
+    Kt = model.k_temporal
+    c, tt, yy = batch(0)
+    c, tt, yy = c.contiguous(), tt.contiguous().view(-1), yy.contiguous()
+    n_prof = 10
+    N.profile_enable(True)
+    for _ in range(n_prof):
+        eng._enqueue(None, c, tt, yy, B, B * world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     if rank == 0:
-        D = model.input_dim
-        H = wl["hidden_dims"]
-        Kt = model.k_temporal
-        c, tt, yy = batch(0)
-        c, tt, yy = c.contiguous(), tt.contiguous().view(-1), yy.contiguous()
-        # ---- per-kernel device time of the step, live, with HIP events on the launch stream
-        n_prof = 10
-        N.profile_enable(True)
-        for _ in range(n_prof):
-            eng._enqueue(None, c, tt, yy, B, B * world)
         recs = N.profile_collect()
         N.profile_enable(False)
         agg = {}
@@ -275,7 +287,7 @@ def main():
             "roofline": roof,
             "rbf_build": {"bound": "hbm", "achieved": rbf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": rbf_gbs / HBM_PEAK_GBS, "bytes_per_obs": 12 + 4 * D, "avg_launch_us": t_rbf * 1e6,
-                          "traffic": None, "note": "both launches of stdadk_rbf_build_f32 (spatial tiles + tail tile)"},
+                          "traffic": None, "note": "one launch of stdadk_rbf_build_f32 over all column tiles"},
             "kernels_us_per_step": kernels_us,
             "kernel_time_us_per_step": round(sum(r[3] for r in per_step), 1),
             "nonzero_obs_knot_pairs_per_obs": nnz / B,

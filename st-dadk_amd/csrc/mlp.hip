@@ -110,14 +110,14 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
   size_t head = (size_t)nblk * (size_t)d->out_dim * (hmax + 1);
   if (head > p->part_floats) p->part_floats = head;
   {
-    const int64_t nb16 = ceil_div(B, TAIL_ROWS);
+    const int64_t nb16 = ceil_div(B, TAIL_MIN_ROWS);
     size_t head16 = (size_t)nb16 * (size_t)d->out_dim * (hmax + 1);
     if (head16 > p->part_floats) p->part_floats = head16;
   }
   p->part = take(p->part_floats);
   for (int l = 0; l < d->n_hidden; ++l) {
     p->dZl[l] = take((size_t)B * d->hidden[l]);
-    p->partl[l] = take((size_t)ceil_div(B, TAIL_ROWS) * 3 * d->hidden[l]);
+    p->partl[l] = take((size_t)ceil_div(B, TAIL_MIN_ROWS) * 3 * d->hidden[l]);
     p->wT[l] = take(l > 0 ? (size_t)d->hidden[l] * d->hidden[l - 1] : 1);
   }
   p->feats = p->psi = p->ypred = p->dY = 0;
@@ -568,7 +568,7 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
     a.y = c.mse_y; a.grad_scale = c.mse_scale; a.dY = c.mse_dY; a.loss_sum = c.mse_loss;
     a.layernorm = d->layernorm; a.eps = d->ln_eps; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
     c.mse_done = c.mse_y != nullptr;
-    { const char *e = getenv("STDADK_TAIL_DEBUG"); a.debug = e ? atoi(e) : 0; }
+    { const char *e = getenv("STDADK_TAIL_STAMPS"); a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     return tail_forward(a, st);
   }
   for (int l = l0; l < L; ++l) {
@@ -606,7 +606,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
 
   if (tail_enabled() && !c.masks && L >= 1 && tail_supported(d, 1)) {
     // one kernel for the whole activation-gradient path, then reductions and the dW GEMMs
-    const int64_t nb16 = ceil_div(B, TAIL_ROWS);
+    const int64_t nb16 = ceil_div(B, tail_rows(B));      // workgroups of the fused backward = partial rows
     const int hL = d->hidden[L - 1];
     TailBwdArgs a;
     a.n_layers = L;

@@ -83,21 +83,26 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   int64_t done = 0;
   if (al) {
     const int64_t n4 = a.n / 4;
+    // m, v and the EMA shadow are pure streams (touched once per step): non-temporal accesses keep
+    // them from evicting the parameters and activations the next step wants in L2 / Infinity Cache
+    typedef float nt4 __attribute__((ext_vector_type(4)));
     for (int64_t j = i0; j < n4; j += stride) {
       float4 p = reinterpret_cast<float4 *>(a.p)[j];
       float4 g = reinterpret_cast<const float4 *>(a.g)[j];
-      float4 m = reinterpret_cast<float4 *>(a.m)[j];
-      float4 v = reinterpret_cast<float4 *>(a.v)[j];
-      float4 e = a.ema ? reinterpret_cast<float4 *>(a.ema)[j] : make_float4(0, 0, 0, 0);
+      nt4 mt = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.m) + j);
+      nt4 vt = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.v) + j);
+      nt4 et = a.ema ? __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.ema) + j) : (nt4){0, 0, 0, 0};
+      float4 m = make_float4(mt.x, mt.y, mt.z, mt.w), v = make_float4(vt.x, vt.y, vt.z, vt.w);
+      float4 e = make_float4(et.x, et.y, et.z, et.w);
       float *ep = a.ema ? &e.x : nullptr;
       adam_one(p.x, g.x, m.x, v.x, ep, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
       adam_one(p.y, g.y, m.y, v.y, ep ? ep + 1 : nullptr, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
       adam_one(p.z, g.z, m.z, v.z, ep ? ep + 2 : nullptr, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
       adam_one(p.w, g.w, m.w, v.w, ep ? ep + 3 : nullptr, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
       reinterpret_cast<float4 *>(a.p)[j] = p;
-      reinterpret_cast<float4 *>(a.m)[j] = m;
-      reinterpret_cast<float4 *>(a.v)[j] = v;
-      if (a.ema) reinterpret_cast<float4 *>(a.ema)[j] = e;
+      __builtin_nontemporal_store((nt4){m.x, m.y, m.z, m.w}, reinterpret_cast<nt4 *>(a.m) + j);
+      __builtin_nontemporal_store((nt4){v.x, v.y, v.z, v.w}, reinterpret_cast<nt4 *>(a.v) + j);
+      if (a.ema) __builtin_nontemporal_store((nt4){e.x, e.y, e.z, e.w}, reinterpret_cast<nt4 *>(a.ema) + j);
     }
     done = n4 * 4;
   }

@@ -19,56 +19,83 @@ constexpr int RB_THREADS = 256;
 // kinds of an output column
 enum { COL_X = 0, COL_S = 1, COL_T = 2, COL_PAD = 3 };
 
-template <int VEC, int BASIS, bool ALL_SPATIAL>
+template <int VEC, int BASIS>
 __global__ __launch_bounds__(RB_THREADS) void rbf_build_kernel(
     const float *__restrict__ coords, const float *__restrict__ t, const float *__restrict__ X,
     int64_t B, int p, const float *__restrict__ s_centers, const float *__restrict__ s_bw,
     int64_t Ks, float cal, const float *__restrict__ t_centers, const float *__restrict__ t_bw,
-    int64_t Kt, float *__restrict__ out, int64_t ld_out, int rows_per_wg, int64_t col_tile0) {
+    int64_t Kt, float *__restrict__ out, int64_t ld_out, int rows_per_wg) {
   const int tid = threadIdx.x;
-  const int64_t tile_c0 = (col_tile0 + blockIdx.x) * (int64_t)TILE_C;
+  const int64_t tile_c0 = (int64_t)blockIdx.x * TILE_C;
   const int64_t row0 = (int64_t)blockIdx.y * rows_per_wg;
   const int64_t row1 = min(row0 + (int64_t)rows_per_wg, B);
   const int64_t D = (int64_t)p + Ks + Kt;
+  // workgroup-uniform: does this column tile lie entirely inside the spatial block [p, p+Ks)?
+  const bool all_spatial = tile_c0 >= p && tile_c0 + TILE_C <= p + Ks;
 
-  // this thread's 4 columns: VEC==4 -> 4 consecutive (one float4 store); VEC==1 -> strided by 256
-  int64_t col[4];
-  float c0[4], c1[4], sc[4];
-  int kind[4];
+  if (all_spatial) {
+    // this thread's 4 columns: VEC==4 -> 4 consecutive (one float4 store); VEC==1 -> strided by 256
+    int64_t col[4];
+    float c0[4], c1[4], sc[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    col[j] = (VEC == 4) ? tile_c0 + 4 * tid + j : tile_c0 + tid + (int64_t)RB_THREADS * j;
-    int64_t c = col[j];
-    c0[j] = 0.f; c1[j] = 0.f; sc[j] = 0.f;
-    if (ALL_SPATIAL || (c >= p && c < p + Ks)) {
-      kind[j] = COL_S;
-      int64_t k = c - p;
+    for (int j = 0; j < 4; ++j) {
+      col[j] = (VEC == 4) ? tile_c0 + 4 * tid + j : tile_c0 + tid + (int64_t)RB_THREADS * j;
+      const int64_t k = col[j] - p;
       c0[j] = s_centers[2 * k];
       c1[j] = s_centers[2 * k + 1];
       sc[j] = knot_scale(s_bw[k], cal);
-    } else if (c < p) {
-      kind[j] = COL_X;
-    } else if (c < D) {
-      kind[j] = COL_T;
-      int64_t k = c - p - Ks;
-      c0[j] = t_centers[k];
-      sc[j] = t_bw[k];
-    } else {
-      kind[j] = COL_PAD;
     }
-  }
-
-  for (int64_t b = row0; b < row1; ++b) {
-    const float x = (ALL_SPATIAL || Ks > 0) ? coords[2 * b] : 0.f;
-    const float y = (ALL_SPATIAL || Ks > 0) ? coords[2 * b + 1] : 0.f;
-    float v[4];
-    if (ALL_SPATIAL) {
+    // hot loop: 4 phi per lane, one 16-byte store per lane and row (1 KiB per wave, 4 KiB per WG)
+    for (int64_t b = row0; b < row1; ++b) {
+      const float x = coords[2 * b], y = coords[2 * b + 1];      // wave-uniform: scalar loads
+      float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = phi_eval<BASIS>(x, y, c0[j], c1[j], sc[j]);
+      for (int j = 0; j < 4; ++j) v[j] = phi_eval<BASIS>(x, y, c0[j], c1[j], sc[j]);
+      float *orow = out + b * ld_out;
+      if (VEC == 4) {
+        *reinterpret_cast<float4 *>(orow + col[0]) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) orow[col[j]] = v[j];
       }
-    } else {
+    }
+    return;
+  }
+  // Edge tiles (covariate copy, temporal basis, zero padding, a few spatial columns): usually only
+  // a fraction of the tile's 1024 columns exists, so the 4 waves split the ROWS (wave w takes rows
+  // row0+w, +4, ...) and each wave sweeps the tile's columns 256 at a time (4 per lane).
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int64_t cbase = tile_c0; cbase < min(tile_c0 + (int64_t)TILE_C, ld_out); cbase += 256) {
+    int64_t col[4];
+    float c0[4], c1[4], sc[4];
+    int kind[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      col[j] = (VEC == 4) ? cbase + 4 * lane + j : cbase + lane + 64 * j;
+      const int64_t c = col[j];
+      c0[j] = 0.f; c1[j] = 0.f; sc[j] = 1.f;
+      if (c >= p && c < p + Ks) {
+        kind[j] = COL_S;
+        const int64_t k = c - p;
+        c0[j] = s_centers[2 * k];
+        c1[j] = s_centers[2 * k + 1];
+        sc[j] = knot_scale(s_bw[k], cal);
+      } else if (c < p) {
+        kind[j] = COL_X;
+      } else if (c < D) {
+        kind[j] = COL_T;
+        const int64_t k = c - p - Ks;
+        c0[j] = t_centers[k];
+        sc[j] = t_bw[k];
+      } else {
+        kind[j] = COL_PAD;
+      }
+    }
+    for (int64_t b = row0 + wave; b < row1; b += RB_THREADS / 64) {
+      const float x = Ks > 0 ? coords[2 * b] : 0.f;
+      const float y = Ks > 0 ? coords[2 * b + 1] : 0.f;
       const float tt = (Kt > 0) ? t[b] : 0.f;
+      float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (kind[j] == COL_S) {
@@ -81,20 +108,14 @@ __global__ __launch_bounds__(RB_THREADS) void rbf_build_kernel(
           v[j] = 0.f;
         }
       }
-    }
-    float *orow = out + b * ld_out;
-    if (VEC == 4) {
-      if (ALL_SPATIAL || col[3] < ld_out) {
+      float *orow = out + b * ld_out;
+      if (VEC == 4 && col[3] < ld_out) {
         *reinterpret_cast<float4 *>(orow + col[0]) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (col[j] < ld_out) orow[col[j]] = v[j];
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (col[j] < ld_out) orow[col[j]] = v[j];
     }
   }
 }
@@ -105,28 +126,14 @@ static void launch_rbf(const float *coords, const float *t, const float *X, int6
                        const float *t_centers, const float *t_bw, int64_t Kt, float *out,
                        int64_t ld_out, hipStream_t st) {
   const int64_t n_tiles = ceil_div(ld_out, TILE_C);
-  // column tiles [sp0, sp1) lie entirely inside the spatial block [p, p+Ks)
-  int64_t sp0 = ceil_div(p, TILE_C), sp1 = (p + Ks) / TILE_C;
-  if (sp1 < sp0) sp1 = sp0;
-  // rows per workgroup: enough workgroups to fill 256 CUs x 8, at least 16 rows each
+  // rows per workgroup: enough workgroups to fill 256 CUs x 8, at least 16 rows each; ONE launch
+  // covers every column tile so the few edge tiles run beside the spatial ones
   int rows = 64;
   while (rows > 16 && ceil_div(B, rows) * n_tiles < 2048) rows >>= 1;
-  const unsigned gy = (unsigned)ceil_div(B, rows);
-  auto go = [&](int64_t t0, int64_t t1, bool all_sp) {
-    if (t1 <= t0) return;
-    dim3 grid((unsigned)(t1 - t0), gy);
-    if (all_sp)
-      STDADK_LAUNCH((rbf_build_kernel<VEC, BASIS, true>), grid, dim3(RB_THREADS), 0, st,
-                         coords, t, X, B, p, s_centers, s_bw, Ks, cal, t_centers, t_bw, Kt, out,
-                         ld_out, rows, t0);
-    else
-      STDADK_LAUNCH((rbf_build_kernel<VEC, BASIS, false>), grid, dim3(RB_THREADS), 0, st,
-                         coords, t, X, B, p, s_centers, s_bw, Ks, cal, t_centers, t_bw, Kt, out,
-                         ld_out, rows, t0);
-  };
-  go(0, sp0 < n_tiles ? sp0 : n_tiles, false);
-  go(sp0, sp1 < n_tiles ? sp1 : n_tiles, true);
-  go(sp1 > sp0 ? sp1 : sp0, n_tiles, false);
+  while (ceil_div(B, rows) > 65535) rows <<= 1;      // gridDim.y limit
+  dim3 grid((unsigned)n_tiles, (unsigned)ceil_div(B, rows));
+  STDADK_LAUNCH((rbf_build_kernel<VEC, BASIS>), grid, dim3(RB_THREADS), 0, st, coords, t, X, B, p, s_centers,
+                s_bw, Ks, cal, t_centers, t_bw, Kt, out, ld_out, rows);
 }
 
 }  // namespace stdadk

@@ -8,7 +8,8 @@
 namespace stdadk {
 
 constexpr int TAIL_MAX_LAYERS = STDADK_MAX_HIDDEN;   // hidden layers handled by one launch
-constexpr int TAIL_ROWS = 16;                        // rows per workgroup (one 16x16x4 MFMA row tile)
+constexpr int TAIL_ROWS = 32;                        // most rows a workgroup carries (tail_rows(B) picks 16 or 32)
+constexpr int TAIL_MIN_ROWS = 16;
 constexpr int TAIL_MAX_W = 256;                      // widest layer the LDS plan holds
 constexpr int TAIL_MAXQ = 8;
 
@@ -41,7 +42,7 @@ struct TailFwdArgs {
   float eps, drop_p;
   uint64_t seed;
   const int *step_dev;
-  int debug;                    // ablation bits (0 in production): 1 skip GEMM, 2 skip LN phase, 4 skip head
+  unsigned long long *stamps;   // -DSTDADK_DIAG builds only: [blocks][16] wall-clock stamps (100 MHz), else NULL
 };
 
 struct TailBwdArgs {
@@ -63,6 +64,7 @@ struct TailBwdArgs {
 };
 
 bool tail_supported(const stdadk_mlp_desc *d, int first_layer);
+int tail_rows(int64_t B);        // rows per workgroup the launches will use for a batch of B rows
 int tail_forward(const TailFwdArgs &a, hipStream_t st);
 int tail_backward(const TailBwdArgs &a, hipStream_t st);
 

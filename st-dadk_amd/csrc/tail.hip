@@ -15,20 +15,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NW = 16;                        // waves per workgroup (4 per SIMD): the phases are latency-bound at
                                               // 16 rows per workgroup, more waves = more loads in flight
 constexpr int TT = 64 * NW;                   // threads per workgroup
-constexpr int RPW = TAIL_ROWS / NW;           // rows per wave in the row-wise phases
 constexpr int MAX_NI = TAIL_MAX_W / 16 / NW;  // N tiles per wave
-constexpr int R = TAIL_ROWS;                  // 16 rows
+constexpr int MAX_MT = TAIL_ROWS / 16;        // 16-row MFMA tiles per workgroup: 1 (small batches: more
+                                              // workgroups than CUs matters) or 2 (weight fragments shared)
 constexpr int ACT_LD = TAIL_MAX_W + 4;        // activation row stride in LDS (floats)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// GLOBAL store (vmcnt(0)); nothing in these kernels reads global data written by another wave.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
 
-// acc[i] (N-tile t = wave + NW i) += A[16 x K] (LDS, row stride ACT_LD) * Wn[N x K]^T where Wn is
-// row-major [N][K] in global memory (K contiguous).  M = 16 is the GEMV-like regime: every wave
-// streams ITS OWN slice of W straight into VGPRs (no LDS staging, no workgroup barrier in the K
-// loop), two 32-deep chunks in flight, 64-byte row pieces per lane group.
 template <int NI>
 struct BFrag { float4 v[2 * NI]; };     // [j*NI + i] : chunk fragment of this lane
 
@@ -51,60 +53,74 @@ __device__ __forceinline__ void load_bfrag(BFrag<NI> &f, const float *__restrict
   }
 }
 
-template <int NI>
-__device__ __forceinline__ void mma_chunk(f32x4 *acc, const BFrag<NI> &f, const float *__restrict__ A, int K, int c,
-                                          int c16, int q) {
+template <int NI, int MT>
+__device__ __forceinline__ void mma_chunk(f32x4 (*acc)[MAX_NI], const BFrag<NI> &f, const float *__restrict__ A, int K,
+                                          int c, int c16, int q) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if (32 * c + 16 * j < K) {          // scalar: K is a multiple of 16, a 16-deep half is all in or out
-      const float4 av = *reinterpret_cast<const float4 *>(A + c16 * ACT_LD + 32 * c + 16 * j + 4 * q);
-      const float af[4] = {av.x, av.y, av.z, av.w};
+      float af[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 av = *reinterpret_cast<const float4 *>(A + (16 * mt + c16) * ACT_LD + 32 * c + 16 * j + 4 * q);
+        af[mt][0] = av.x; af[mt][1] = av.y; af[mt][2] = av.z; af[mt][3] = av.w;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {   // consecutive MFMAs hit different accumulators
+        for (int i = 0; i < NI; ++i) {
           const float4 bv = f.v[j * NI + i];
           const float bf[4] = {bv.x, bv.y, bv.z, bv.w};
-          acc[i] = mfma16(af[e], bf[e], acc[i]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)      // every weight fragment feeds both row tiles
+            acc[mt][i] = mfma16(af[mt][e], bf[e], acc[mt][i]);
         }
       }
     }
   }
 }
 
-template <int NI>
-__device__ __forceinline__ void gemm16_ni(f32x4 *acc, const float *__restrict__ A, const float *__restrict__ Wn,
+template <int NI, int MT>
+__device__ __forceinline__ void gemm16_ni(f32x4 (*acc)[MAX_NI], const float *__restrict__ A, const float *__restrict__ Wn,
                                           int K, int wave, int c16, int q) {
   const int nchunk = (K + 31) >> 5;
   BFrag<NI> f0, f1;
   load_bfrag<NI>(f0, Wn, K, 0, wave, c16, q);
   for (int c = 0; c < nchunk; c += 2) {
     if (c + 1 < nchunk) load_bfrag<NI>(f1, Wn, K, c + 1, wave, c16, q);
-    mma_chunk<NI>(acc, f0, A, K, c, c16, q);
+    mma_chunk<NI, MT>(acc, f0, A, K, c, c16, q);
     if (c + 1 < nchunk) {
       if (c + 2 < nchunk) load_bfrag<NI>(f0, Wn, K, c + 2, wave, c16, q);
-      mma_chunk<NI>(acc, f1, A, K, c + 1, c16, q);
+      mma_chunk<NI, MT>(acc, f1, A, K, c + 1, c16, q);
     }
   }
 }
 
-// acc[i] (N-tile t = wave + NW i) += A[16 x K] (LDS, row stride ACT_LD) * Wn[N x K]^T where Wn is
+// acc[mt][i] (rows 16 mt.., N-tile t = wave + NW i) += A[R x K] (LDS, row stride ACT_LD) * Wn[N x K]^T where Wn is
 // row-major [N][K] in global memory (K contiguous).  M = 16 is the GEMV-like regime: every wave
 // streams ITS OWN slice of W straight into VGPRs (no LDS staging, no workgroup barrier in the K
 // loop), two 32-deep chunks in flight, 64-byte row pieces per lane group.
-__device__ __forceinline__ void gemm16(f32x4 *acc, const float *__restrict__ A, const float *__restrict__ Wn, int N,
+template <int MT>
+__device__ __forceinline__ void gemm16(f32x4 (*acc)[MAX_NI], const float *__restrict__ A, const float *__restrict__ Wn, int N,
                                        int K, int wave, int c16, int q) {
   const int NT = N >> 4;
   const int ni = (NT - wave + NW - 1) / NW;   // tiles wave, wave+NW, ... < NT   (wave is scalar)
   static_assert(MAX_NI <= 2, "dispatch below assumes at most 2 tiles per wave");
-  if (MAX_NI >= 2 && ni >= 2) gemm16_ni<(MAX_NI >= 2 ? 2 : 1)>(acc, A, Wn, K, wave, c16, q);
-  else if (ni >= 1) gemm16_ni<1>(acc, A, Wn, K, wave, c16, q);
+  if (MAX_NI >= 2 && ni >= 2) gemm16_ni<(MAX_NI >= 2 ? 2 : 1), MT>(acc, A, Wn, K, wave, c16, q);
+  else if (ni >= 1) gemm16_ni<1, MT>(acc, A, Wn, K, wave, c16, q);
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+#ifdef STDADK_DIAG   // diagnostic build only: in-kernel wall-clock stamps of the phases
+#define STAMP(i) do { if (a.stamps && tid == 0) a.stamps[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+template <int MT>
 __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
+  constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *act0 = smem, *act1 = smem + R * ACT_LD;
   __shared__ float red[TT / 64];
@@ -112,13 +128,12 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = blockIdx.x * R;
-  for (int i = tid; i < 2 * R * ACT_LD; i += TT) smem[i] = 0.f;   // pads must be finite (x0 later)
-  __syncthreads();
+  STAMP(0);
   {
     // input tile: unconditional loads from clamped rows (rows >= B duplicate the last row; nothing
     // computed for them is ever stored), 4 per thread in flight
-    const int v4 = a.h_in >> 2;            // <= 64 float4 per row => R*v4 <= 1024
-    constexpr int NLD = 1024 / TT;
+    const int v4 = a.h_in >> 2;            // <= 64 float4 per row => R*v4 <= 64*R
+    constexpr int NLD = 64 * R / TT;
     float4 tv[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -135,19 +150,23 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   float *cur = act0, *nxt = act1;
+  STAMP(1);
 
   for (int li = 0; li < a.n_layers; ++li) {
     const TailLayer &L = a.L[li];
     const int h = L.h, hp = L.hp;
     const int NT = h >> 4;
-    f32x4 acc[MAX_NI];
+    f32x4 acc[MT][MAX_NI];
 #pragma unroll
-    for (int i = 0; i < MAX_NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!(a.debug & 1)) gemm16(acc, cur, L.W, h, hp, wave, c16, q);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm16<MT>(acc, cur, L.W, h, hp, wave, c16, q);
+    STAMP(2 + 4 * li);
     // z = acc + bias into the other activation buffer
 #pragma unroll
     for (int i = 0; i < MAX_NI; ++i) {
@@ -156,10 +175,13 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
         const int col = 16 * t + c16;
         const float bv = L.b[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nxt[(4 * q + r) * ACT_LD + col] = acc[i][r] + bv;
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nxt[(16 * mt + 4 * q + r) * ACT_LD + col] = acc[mt][i][r] + bv;
       }
     }
-    __syncthreads();
+    lds_barrier();
+    STAMP(3 + 4 * li);
     // LayerNorm -> ReLU -> Dropout, wave w owns rows RPW*w .. RPW*w+RPW-1.  gamma/beta are loaded once per
     // layer from clamped columns (no conditional loads: each would cost its own L2 round trip).
     float gv[4], bev[4];
@@ -169,7 +191,6 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
       gv[cc] = a.layernorm ? L.g[colc] : 1.f;
       bev[cc] = a.layernorm ? L.be[colc] : 0.f;
     }
-    if (!(a.debug & 2))
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = RPW * wave + rr;
@@ -213,14 +234,15 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
         }
       }
     }
-    __syncthreads();
+    STAMP(4 + 4 * li);
+    lds_barrier();
+    STAMP(5 + 4 * li);
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
 
   // output layer (+ MSE): y[row][qq] = a_last[row,:] . Wo[qq,:] + bo[qq]
   const int hl = a.n_layers ? a.L[a.n_layers - 1].h : a.h_in;
   float lsum = 0.f;
-  if (!(a.debug & 4))
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = RPW * wave + rr;
@@ -240,9 +262,10 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
       }
     }
   }
+  STAMP(14);
   if (a.y && a.loss_sum) {
     if (lane == 0) red[wave] = lsum;
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
       float t = 0.f;
 #pragma unroll
@@ -255,7 +278,9 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // backward (data path): dA / dZ of every hidden layer + column partials for dgamma, dbeta, db
 // ---------------------------------------------------------------------------------------------
+template <int MT>
 __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
+  constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *d0 = smem, *d1 = smem + R * ACT_LD;
   float *red = smem + 2 * R * ACT_LD;                // [3][NW][256]
@@ -264,12 +289,11 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = blockIdx.x * R;
-  for (int i = tid; i < 2 * R * ACT_LD; i += TT) smem[i] = 0.f;
   if (tid < R * TAIL_MAXQ) {
     const int row = tid / a.Q, qq = tid - row * a.Q;
     sdy[tid] = (tid < R * a.Q && row0 + row < a.B) ? a.dY[(size_t)(row0 + row) * a.Q + qq] : 0.f;
   }
-  __syncthreads();
+  lds_barrier();
   const int hl = a.L[a.n_layers - 1].h;
   for (int idx = tid; idx < R * hl; idx += TT) {
     const int row = idx / hl, col = idx - row * hl;
@@ -301,7 +325,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
       ph[a.Q * hl + tid] = sb;
     }
   }
-  __syncthreads();
+  lds_barrier();
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   float *cur = d0, *nxt = d1;
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
       red[(1 * NW + wave) * 256 + lane + 64 * cc] = pb[cc];
       red[(2 * NW + wave) * 256 + lane + 64 * cc] = pz[cc];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < h) {
       float *pbase = a.part[li] + (size_t)blockIdx.x * 3 * h;
 #pragma unroll
@@ -393,20 +417,24 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
     // ---- (b) dA_prev[16 x hp] = dZ[16 x h] W[h x hp], with W^T ([hp][h], K contiguous) as the B operand
     const int hp = L.hp;
     const int NT = hp >> 4;
-    f32x4 acc[MAX_NI];
+    f32x4 acc[MT][MAX_NI];
 #pragma unroll
-    for (int i = 0; i < MAX_NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();                 // every wave's dZ rows are in `cur`
-    gemm16(acc, cur, a.WT[li], hp, h, wave, c16, q);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    lds_barrier();                 // every wave's dZ rows are in `cur`
+    gemm16<MT>(acc, cur, a.WT[li], hp, h, wave, c16, q);
 #pragma unroll
     for (int i = 0; i < MAX_NI; ++i) {
       const int t = wave + NW * i;
       if (t < NT) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nxt[(4 * q + r) * ACT_LD + 16 * t + c16] = acc[i][r];
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nxt[(16 * mt + 4 * q + r) * ACT_LD + 16 * t + c16] = acc[mt][i][r];
       }
     }
-    __syncthreads();
+    lds_barrier();
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
 }
@@ -436,19 +464,46 @@ bool tail_supported(const stdadk_mlp_desc *d, int first_layer) {
   return true;
 }
 
-static size_t fwd_lds() { return (2 * R * ACT_LD) * sizeof(float); }
-static size_t bwd_lds() { return (2 * R * ACT_LD + 3 * NW * 256 + R * TAIL_MAXQ) * sizeof(float); }
+static size_t fwd_lds(int R) { return (size_t)(2 * R * ACT_LD) * sizeof(float); }
+static size_t bwd_lds(int R) { return (size_t)(2 * R * ACT_LD + 3 * NW * 256 + R * TAIL_MAXQ) * sizeof(float); }
 
-int tail_forward(const TailFwdArgs &a, hipStream_t st) {
+int tail_rows(int64_t B) {
+  // two 16-row tiles per workgroup (shared weight fragments) once that still gives every CU a
+  // workgroup; one tile per workgroup for small batches
+  return ceil_div(B, 32) >= 256 ? 32 : 16;
+}
+
+template <int MT>
+static int launch_fwd(const TailFwdArgs &a, hipStream_t st) {
+  constexpr int R = 16 * MT;
   static bool attr_done = false;
   if (!attr_done) {   // once per process, never inside a stream capture (the first step runs eagerly)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds());
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel<MT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds(R));
     if (e != hipSuccess) { set_error("tail_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  STDADK_LAUNCH(tail_fwd_kernel, dim3((unsigned)ceil_div(a.B, R)), dim3(TT), fwd_lds(), st, a);
+  STDADK_LAUNCH_NAMED("tail_fwd_kernel", (tail_fwd_kernel<MT>), dim3((unsigned)ceil_div(a.B, R)), dim3(TT), fwd_lds(R), st, a);
   STDADK_CHECK_LAUNCH("tail_forward");
+  return 0;
+}
+
+int tail_forward(const TailFwdArgs &a, hipStream_t st) {
+  return tail_rows(a.B) == 32 ? launch_fwd<2>(a, st) : launch_fwd<1>(a, st);
+}
+
+template <int MT>
+static int launch_bwd(const TailBwdArgs &a, hipStream_t st) {
+  constexpr int R = 16 * MT;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel<MT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds(R));
+    if (e != hipSuccess) { set_error("tail_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  STDADK_LAUNCH_NAMED("tail_bwd_kernel", (tail_bwd_kernel<MT>), dim3((unsigned)ceil_div(a.B, R)), dim3(TT), bwd_lds(R), st, a);
+  STDADK_CHECK_LAUNCH("tail_backward");
   return 0;
 }
 
@@ -468,16 +523,7 @@ int tail_backward(const TailBwdArgs &a, hipStream_t st) {
                   dim3(256), 0, st, t);
     STDADK_CHECK_LAUNCH("tail_transpose");
   }
-  static bool attr_done = false;
-  if (!attr_done) {   // once per process, never inside a stream capture (the first step runs eagerly)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds());
-    if (e != hipSuccess) { set_error("tail_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
-  STDADK_LAUNCH(tail_bwd_kernel, dim3((unsigned)ceil_div(a.B, R)), dim3(TT), bwd_lds(), st, a);
-  STDADK_CHECK_LAUNCH("tail_backward");
-  return 0;
+  return tail_rows(a.B) == 32 ? launch_bwd<2>(a, st) : launch_bwd<1>(a, st);
 }
 
 }  // namespace stdadk

@@ -124,16 +124,25 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const float *__restrict
                                                          float *__restrict__ y_s, float *__restrict__ X_s) {
   __shared__ int hist[SMALL_G * SMALL_G];      // counts, then running cursors
   __shared__ int start[SMALL_G * SMALL_G + 1];
-  __shared__ int ptmp[SMALL_B];
+  __shared__ int ptmp[SMALL_B];                // unordered permutation
+  __shared__ int pfin[SMALL_B];                // ordered permutation
   __shared__ int part[1024];
   const int tid = threadIdx.x;
   const int ncell = G * G;
+  constexpr int PER_T = SMALL_B / 1024;        // observations per thread
   for (int c = tid; c < ncell; c += 1024) hist[c] = 0;
   __syncthreads();
-  for (int b = tid; b < B; b += 1024) {
-    const int c = cell_of(coords[2 * b], coords[2 * b + 1], G);
-    keys[b] = c;
-    atomicAdd(&hist[c], 1);
+  int kk[PER_T];
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {
+    const int b = tid + 1024 * i;
+    const int bc = min(b, B - 1);
+    kk[i] = cell_of(coords[2 * bc], coords[2 * bc + 1], G);     // unconditional, clamped
+  }
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {
+    const int b = tid + 1024 * i;
+    if (b < B) { keys[b] = kk[i]; atomicAdd(&hist[kk[i]], 1); }
   }
   __syncthreads();
   // exclusive scan: thread tid owns cells [tid*per, tid*per+per)
@@ -159,23 +168,35 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const float *__restrict
   }
   if (tid == 1023) { start[ncell] = part[1023]; cell_start[ncell] = part[1023]; }
   __syncthreads();
-  for (int b = tid; b < B; b += 1024) {
-    const int pos = atomicAdd(&hist[keys[b]], 1);
-    ptmp[pos] = b;
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {
+    const int b = tid + 1024 * i;
+    if (b < B) ptmp[atomicAdd(&hist[kk[i]], 1)] = b;
   }
   __syncthreads();
-  // order every cell by original index (rank by counting) and emit the sorted arrays
+  // order every cell by original index (rank by counting): LDS only
   for (int c = tid; c < ncell; c += 1024) {
     const int s0 = start[c], s1 = start[c + 1];
     for (int i = s0; i < s1; ++i) {
       const int b = ptmp[i];
       int rank = 0;
       for (int j = s0; j < s1; ++j) rank += ptmp[j] < b;
-      const int pos = s0 + rank;
+      pfin[s0 + rank] = b;
+    }
+  }
+  __syncthreads();
+  // emit the sorted arrays: one position per thread and pass, independent loads
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {
+    const int pos = tid + 1024 * i;
+    const int b = pfin[min(pos, B - 1)];
+    const float cx = coords[2 * b], cy = coords[2 * b + 1];
+    const float tv = t ? t[b] : 0.f;
+    if (pos < B) {
       perm[pos] = b;
-      xs[pos] = coords[2 * b];
-      ys[pos] = coords[2 * b + 1];
-      if (t) ts[pos] = t[b];
+      xs[pos] = cx;
+      ys[pos] = cy;
+      if (t) ts[pos] = tv;
       if (y_s)
         for (int q = 0; q < Q; ++q) y_s[(int64_t)pos * Q + q] = y[(int64_t)b * Q + q];
       if (X_s)

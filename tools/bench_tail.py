@@ -1,4 +1,4 @@
-"""Ablation timing of the fused tail forward kernel (debug env STDADK_TAIL_DEBUG)."""
+"""Per-kernel HIP-event timing of one engine step (tail / window kernels)."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "st-dadk_amd")):
@@ -26,4 +26,4 @@ N.profile_enable(False)
 agg = {}
 for n, ms in recs:
     a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += ms
-print("debug", os.environ.get("STDADK_TAIL_DEBUG", "0"), {k: round(v[1] / v[0] * 1e3, 1) for k, v in agg.items() if "tail" in k or "window" in k})
+print({k: round(v[1] / v[0] * 1e3, 1) for k, v in agg.items()})
