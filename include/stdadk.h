@@ -205,13 +205,16 @@ int stdadk_backward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *m
 /* A2-A8 in one call: training forward, nn.MSELoss and its gradient, backward:
  *   loss_sum[0] += sum((y_pred-y)^2);  grads = d/dparams of grad_scale * sum((y_pred-y)^2)
  * (grad_scale = 1/(rows*Q) of the GLOBAL batch, so summing the ranks' gradients gives the global
- * mean).  y [B,Q]; y_pred [B,Q] (caller's row order) is optional: NULL skips writing it. */
+ * mean).  y [B,Q]; y_pred [B,Q] (caller's row order) is optional: NULL skips writing it.
+ * aux_stream (optional, NULL = none): a second stream onto which independent kernels of the step
+ * are forked (event fork/join, capturable); on return every kernel has been joined into `stream`. */
 int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
                              const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,
                              const float *coords, const float *t, const float *X, const float *y,
                              int64_t B, float grad_scale, float *loss_sum, float *y_pred,
                              void *workspace, size_t workspace_bytes, uint64_t drop_seed,
-                             const int32_t *step_dev, int32_t flags, stdadk_stream_t stream);
+                             const int32_t *step_dev, int32_t flags, stdadk_stream_t stream,
+                             stdadk_stream_t aux_stream);
 
 /* A0  batch producer (scripts/train_st_interp.py:413-460 dataset + collate, :609-612 H2D): rows
  * idx[b] (int64) of the device-resident observation arrays into contiguous batch buffers, one launch.

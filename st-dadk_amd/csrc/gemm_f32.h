@@ -39,6 +39,7 @@ struct ReduceJob {
   float *dst;         // dst[i] = sum_s
   int n, splits;
   int64_t stride;
+  int wide = 0;       // set by launch_reduce_jobs
 };
 constexpr int REDUCE_GROUP_MAX = 40;
 struct ReduceGroup {

@@ -238,32 +238,41 @@ __global__ __launch_bounds__(GT) void gemm_tn_grouped_kernel(GemmGroup grp) {
   gemm_tile_body<64, 64, true, true, 4, 4>(g, b % tn, b / tn, bz, lds);
 }
 
-// dst_j[i] = sum_s src_j[s*stride_j + i], i < n_j, for a table of jobs (split-K slabs, per-workgroup
-// column partials): 64 columns x 16 s-groups per workgroup, fixed summation order.
-__global__ __launch_bounds__(1024) void reduce_jobs_kernel(ReduceGroup grp) {
-  __shared__ float red[16][64];
+// dst_j[i] = sum_s src_j[s*stride_j + i], i < n_j, for a table of jobs, fixed summation order.
+//   tall jobs (many partials, few columns: per-workgroup column partials): 64 columns x 4 s-groups
+//   wide jobs (few partials, many columns: split-K slabs): one float4 of columns per thread, the
+//              (<= 64) partials summed serially with independent, coalesced loads
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceGroup grp) {
+  __shared__ float red[4][64];
   int j = 0;
   while (j + 1 < grp.n && (int)blockIdx.x >= grp.first_block[j + 1]) ++j;
   const ReduceJob &jb = grp.job[j];
+  const int blk = blockIdx.x - grp.first_block[j];
+  if (jb.wide) {
+    const int c = (blk * 256 + threadIdx.x) * 4;
+    if (c >= jb.n) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < jb.splits; ++s) {
+      const float4 v = *reinterpret_cast<const float4 *>(jb.src + (int64_t)s * jb.stride + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(jb.dst + c) = acc;
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = (blockIdx.x - grp.first_block[j]) * 64 + tx;
+  const int c = blk * 64 + tx;
   float s0 = 0.f, s1 = 0.f;
   if (c < jb.n) {
     int s = ty;
-    for (; s + 16 < jb.splits; s += 32) {
+    for (; s + 4 < jb.splits; s += 8) {
       s0 += jb.src[(int64_t)s * jb.stride + c];
-      s1 += jb.src[(int64_t)(s + 16) * jb.stride + c];
+      s1 += jb.src[(int64_t)(s + 4) * jb.stride + c];
     }
-    for (; s < jb.splits; s += 16) s0 += jb.src[(int64_t)s * jb.stride + c];
+    for (; s < jb.splits; s += 4) s0 += jb.src[(int64_t)s * jb.stride + c];
   }
   red[ty][tx] = s0 + s1;
   __syncthreads();
-  if (ty == 0 && c < jb.n) {
-    float v = 0.f;
-#pragma unroll
-    for (int gq = 0; gq < 16; ++gq) v += red[gq][tx];
-    jb.dst[c] = v;
-  }
+  if (ty == 0 && c < jb.n) jb.dst[c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
 int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st) {
@@ -284,11 +293,14 @@ int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st) {
 int launch_reduce_jobs(ReduceGroup &grp, hipStream_t st) {
   int nb = 0;
   for (int j = 0; j < grp.n; ++j) {
+    ReduceJob &jb = grp.job[j];
+    jb.wide = jb.splits <= 64 && jb.n % 4 == 0 && jb.stride % 4 == 0 &&
+              ((reinterpret_cast<uintptr_t>(jb.src) | reinterpret_cast<uintptr_t>(jb.dst)) & 15) == 0;
     grp.first_block[j] = nb;
-    nb += (int)ceil_div(grp.job[j].n, 64);
+    nb += (int)ceil_div(jb.n, jb.wide ? 1024 : 64);
   }
   if (nb == 0) return 0;
-  STDADK_LAUNCH(reduce_jobs_kernel, dim3((unsigned)nb), dim3(1024), 0, st, grp);
+  STDADK_LAUNCH(reduce_jobs_kernel, dim3((unsigned)nb), dim3(256), 0, st, grp);
   STDADK_CHECK_LAUNCH("reduce_jobs");
   return 0;
 }

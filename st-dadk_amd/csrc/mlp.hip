@@ -450,6 +450,7 @@ static int check_desc(const stdadk_mlp_desc *d) {
   return 0;
 }
 
+struct Ctx;
 struct Ctx {
   const stdadk_mlp_desc *d;
   const stdadk_mlp_tensors *P;
@@ -470,11 +471,39 @@ struct Ctx {
   float *mse_loss = nullptr;
   bool mse_done = false;        // set by run_forward when the loss was fused into the tail kernel
   const float *dz0 = nullptr;   // set by run_backward: dZ of layer 0
+  // optional second stream: independent kernels of a step fork onto it (hipGraph-capturable
+  // fork/join through events); NULL = everything on `st`
+  hipStream_t aux = nullptr;
+  bool wt_ready = false;
+  int (*fork_after_dz)(Ctx &) = nullptr;   // called by run_backward (fused tail) right after the dZ kernel
+  const stdadk_basis_desc *basis = nullptr;
+  bool dw0_forked = false;        // W^T scratch of the fused backward already produced (on aux)
   // extra products C[M][H0] = A^T dZ_0 (reduction over the batch) to run with the dW GEMMs of the
   // fused-tail backward: the temporal / covariate rows of dW0^T on the window path
   int n_extra = 0;
   struct { const float *A; int64_t lda; int M; float *C; } extra[2];
 };
+
+// fork/join between the main and the auxiliary stream (events are created once per thread)
+static hipEvent_t *fork_events() {
+  static thread_local hipEvent_t ev[4];
+  static thread_local bool made = false;
+  if (!made) {
+    for (int i = 0; i < 4; ++i)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    made = true;
+  }
+  return ev;
+}
+// `to` waits for everything enqueued on `from` so far
+static int stream_depends(hipStream_t to, hipStream_t from, int slot) {
+  hipEvent_t *ev = fork_events();
+  STDADK_REQUIRE(ev != nullptr, STDADK_E_ARG, "could not create fork/join events");
+  hipError_t e = hipEventRecord(ev[slot], from);
+  if (e == hipSuccess) e = hipStreamWaitEvent(to, ev[slot], 0);
+  if (e != hipSuccess) { set_error("stream fork/join: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
 
 static bool tail_enabled() {
   static int v = -1;
@@ -622,9 +651,18 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     a.B = (int)B; a.Wo = P->W[L]; a.Q = Q; a.dY = dY;
     a.act_last = ws + pl.act[L - 1]; a.part_head = part;
     a.layernorm = d->layernorm; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
+    if (!c.wt_ready) {
+      rc = tail_transpose_weights(a, st);
+      if (rc) return rc;
+    }
+    c.wt_ready = false;
     rc = tail_backward(a, st);
     if (rc) return rc;
     c.dz0 = ws + pl.dZl[0];
+    if (c.fork_after_dz) {       // dZ of every layer is final: independent consumers may start now
+      rc = c.fork_after_dz(c);
+      if (rc) return rc;
+    }
     // ---- ONE grouped launch for the dW products, ONE grouped launch for every fixed-order sum
     GemmGroup gg;
     ReduceGroup rg;
@@ -930,6 +968,19 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
   return 0;
 }
 
+// dW0^T spatial rows (window path): every knot row by the wave that owns it
+static int window_dw0(Ctx &c, hipStream_t st) {
+  const stdadk_basis_desc *b = c.basis;
+  float *ws = c.ws;
+  L1BwdArgs a;
+  a.g = make_grid(b);
+  a.xs = ws + c.pl.xs; a.ys = ws + c.pl.ys;
+  a.cell_start = (const int *)(ws + c.pl.cell_start);
+  a.G = c.pl.G; a.B = (int)c.B; a.H = c.d->hidden[0];
+  a.dZ = c.dz0; a.dW0T = c.G->W[0];
+  return l1_window_backward(a, b->basis, st);
+}
+
 // forward of one batch; training != 0 keeps everything backward needs in the workspace
 // (window path: `y`, when given, is carried into sorted order next to the observations, and the
 //  predictions stay in sorted order in the plan's ypred buffer; y_pred NULL skips the un-permute)
@@ -977,7 +1028,24 @@ static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const 
     ++c.n_extra;
   }
   STDADK_REQUIRE(c.G->W[0], STDADK_E_ARG, "backward: dW[0] NULL");
+  c.basis = b;
+  c.dw0_forked = false;
+  if (c.aux) {
+    if (c.wt_ready) {            // the W^T scratch was produced on the auxiliary stream
+      rc = stream_depends(c.st, c.aux, 1);
+      if (rc) return rc;
+    }
+    // as soon as dZ is final, the knot-row gather of dW0^T runs on the auxiliary stream beside the
+    // dW GEMMs and reductions of the other layers
+    c.fork_after_dz = [](Ctx &cc) -> int {
+      int r = stream_depends(cc.aux, cc.st, 2);
+      if (r) return r;
+      cc.dw0_forked = true;
+      return window_dw0(cc, cc.aux);
+    };
+  }
   rc = run_backward(c, ws + c.pl.dY, nullptr, 0, false);
+  c.fork_after_dz = nullptr;
   if (rc) return rc;
   for (int e = 0; e < c.n_extra; ++e) {     // not consumed by a grouped launch
     rc = gemm_run(c.extra[e].A, c.extra[e].lda, true, c.dz0, H, true, c.extra[e].M, H, (int)c.B, nullptr,
@@ -985,14 +1053,8 @@ static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const 
     if (rc) return rc;
   }
   c.n_extra = 0;
-  // dW0^T spatial rows: every knot row by the wave that owns it
-  L1BwdArgs a;
-  a.g = make_grid(b);
-  a.xs = ws + c.pl.xs; a.ys = ws + c.pl.ys;
-  a.cell_start = (const int *)(ws + c.pl.cell_start);
-  a.G = c.pl.G; a.B = (int)c.B; a.H = H;
-  a.dZ = c.dz0; a.dW0T = c.G->W[0];
-  return l1_window_backward(a, b->basis, c.st);
+  if (c.dw0_forked) return stream_depends(c.st, c.aux, 3);      // join
+  return window_dw0(c, c.st);
 }
 
 extern "C" int stdadk_forward_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
@@ -1033,17 +1095,31 @@ extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk
                                         const float *y, int64_t B, float grad_scale, float *loss_sum,
                                         float *y_pred, void *workspace, size_t workspace_bytes,
                                         uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
-                                        stdadk_stream_t stream) {
+                                        stdadk_stream_t stream, stdadk_stream_t aux_stream) {
   if (B == 0) return 0;
   Ctx c;
   bool window;
   int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
   if (rc) return rc;
   STDADK_REQUIRE(P && G && coords && t && y, STDADK_E_ARG, "train_fwd_bwd: NULL pointer");
+  c.aux = (aux_stream && aux_stream != stream) ? (hipStream_t)aux_stream : nullptr;
   STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "train_fwd_bwd: X is NULL with p=%d", b->p);
   c.P = P; c.G = G; c.st = (hipStream_t)stream; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = step_dev;
   const int64_t n = B * d->out_dim;
   c.mse_scale = grad_scale; c.mse_dY = c.ws + c.pl.dY; c.mse_loss = loss_sum;
+  if (window && c.aux && tail_enabled() && d->n_hidden > 1 && tail_supported(d, 1)) {
+    // fork: the W^T scratch of the fused backward does not depend on this batch
+    c.P = P;
+    rc = stream_depends(c.aux, (hipStream_t)stream, 0);
+    if (rc) return rc;
+    TailBwdArgs ta;
+    ta.n_layers = d->n_hidden;
+    c.ws = (float *)workspace;
+    for (int l = 0; l < d->n_hidden; ++l) { ta.L[l] = tail_layer(c, l); ta.WT[l] = c.ws + c.pl.wT[l]; }
+    rc = tail_transpose_weights(ta, c.aux);
+    if (rc) return rc;
+    c.wt_ready = true;
+  }
   if (window) {
     // everything between the binning and the weight gradients stays in sorted order
     c.mse_y = c.ws + c.pl.y_s;

@@ -54,7 +54,7 @@ struct TailBwdArgs {
   const float *dY;              // [B][Q]
   const float *act_last;        // [B][h_last] activations feeding the output layer
   float *part_head;             // [nblk][Q*h_last | Q] partials of dWo then dbo
-  float *WT[TAIL_MAX_LAYERS];   // [hp_l][h_l] scratch: W_l transposed (filled by tail_backward), l >= 1
+  float *WT[TAIL_MAX_LAYERS];   // [hp_l][h_l] scratch: W_l transposed (tail_transpose_weights), l >= 1
   float *dZ[TAIL_MAX_LAYERS];   // [B][h_l] out: gradient w.r.t. the pre-LayerNorm output of layer l
   float *part[TAIL_MAX_LAYERS]; // [nblk][3][h_l] column partials (dgamma, dbeta, db) per workgroup
   int layernorm;
@@ -66,6 +66,7 @@ struct TailBwdArgs {
 bool tail_supported(const stdadk_mlp_desc *d, int first_layer);
 int tail_rows(int64_t B);        // rows per workgroup the launches will use for a batch of B rows
 int tail_forward(const TailFwdArgs &a, hipStream_t st);
-int tail_backward(const TailBwdArgs &a, hipStream_t st);
+int tail_transpose_weights(const TailBwdArgs &a, hipStream_t st);   // fills a.WT (needs only L[].W/h/hp, WT)
+int tail_backward(const TailBwdArgs &a, hipStream_t st);            // a.WT must be ready
 
 }  // namespace stdadk

@@ -507,22 +507,27 @@ static int launch_bwd(const TailBwdArgs &a, hipStream_t st) {
   return 0;
 }
 
-int tail_backward(const TailBwdArgs &a, hipStream_t st) {
-  if (a.n_layers > 1) {
-    TransArgs t;
-    t.n = a.n_layers - 1;
-    int hmax = 0, hpmax = 0;
-    for (int li = 1; li < a.n_layers; ++li) {
-      t.W[li - 1] = a.L[li].W; t.WT[li - 1] = a.WT[li];
-      t.h[li - 1] = a.L[li].h; t.hp[li - 1] = a.L[li].hp;
-      hmax = a.L[li].h > hmax ? a.L[li].h : hmax;
-      hpmax = a.L[li].hp > hpmax ? a.L[li].hp : hpmax;
-    }
-    for (int li = t.n; li < TAIL_MAX_LAYERS; ++li) { t.W[li] = nullptr; t.WT[li] = nullptr; t.h[li] = t.hp[li] = 0; }
-    STDADK_LAUNCH(tail_transpose_kernel, dim3((unsigned)ceil_div(hpmax, 32), (unsigned)ceil_div(hmax, 32), (unsigned)t.n),
-                  dim3(256), 0, st, t);
-    STDADK_CHECK_LAUNCH("tail_transpose");
+// WT[l] = W_l^T for the layers whose dA product the backward kernel runs (l >= 1); may run on another
+// stream than tail_backward as long as it has finished before.
+int tail_transpose_weights(const TailBwdArgs &a, hipStream_t st) {
+  if (a.n_layers <= 1) return 0;
+  TransArgs t;
+  t.n = a.n_layers - 1;
+  int hmax = 0, hpmax = 0;
+  for (int li = 1; li < a.n_layers; ++li) {
+    t.W[li - 1] = a.L[li].W; t.WT[li - 1] = a.WT[li];
+    t.h[li - 1] = a.L[li].h; t.hp[li - 1] = a.L[li].hp;
+    hmax = a.L[li].h > hmax ? a.L[li].h : hmax;
+    hpmax = a.L[li].hp > hpmax ? a.L[li].hp : hpmax;
   }
+  for (int li = t.n; li < TAIL_MAX_LAYERS; ++li) { t.W[li] = nullptr; t.WT[li] = nullptr; t.h[li] = t.hp[li] = 0; }
+  STDADK_LAUNCH(tail_transpose_kernel, dim3((unsigned)ceil_div(hpmax, 32), (unsigned)ceil_div(hmax, 32), (unsigned)t.n),
+                dim3(256), 0, st, t);
+  STDADK_CHECK_LAUNCH("tail_transpose");
+  return 0;
+}
+
+int tail_backward(const TailBwdArgs &a, hipStream_t st) {
   return tail_rows(a.B) == 32 ? launch_bwd<2>(a, st) : launch_bwd<1>(a, st);
 }
 

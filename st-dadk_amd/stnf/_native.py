@@ -74,7 +74,7 @@ _SIGNATURES = {
                                            C.POINTER(MlpTensors), C.POINTER(MlpTensors), C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
-                                           C.c_void_p, C.c_int32, C.c_void_p]),
+                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "stdadk_gather_batch_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -288,13 +288,14 @@ def backward(basis, desc, params, grads, B, dY, workspace, flags, seed=0, step_d
 
 
 def train_fwd_bwd(basis, desc, params, grads, coords, t, X, y, B, grad_scale, loss_sum, y_pred,
-                  workspace, flags, seed=0, step_dev=None):
+                  workspace, flags, seed=0, step_dev=None, aux_stream=None):
     rc = lib().stdadk_train_fwd_bwd_f32(C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads),
                                         _dev(coords, "coords"), _dev(t, "t"), _dev(X, "X"), _dev(y, "y"),
                                         B, grad_scale, _dev(loss_sum, "loss_sum"), _dev(y_pred, "y_pred"),
                                         workspace.data_ptr(),
                                         workspace.numel() * workspace.element_size(), seed,
-                                        _dev(step_dev, "step_dev"), flags, _stream())
+                                        _dev(step_dev, "step_dev"), flags, _stream(),
+                                        aux_stream.cuda_stream if aux_stream is not None else None)
     _check(rc, "stdadk_train_fwd_bwd_f32")
 
 

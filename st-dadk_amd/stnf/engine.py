@@ -52,7 +52,7 @@ class TrainStep:
 
     def __init__(self, model, lr=2e-2, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
                  grad_clip=10.0, ema_decay=None, max_batch=4096, use_graph=False,
-                 process_group=None, distributed=None, force_dense=False):
+                 process_group=None, distributed=None, force_dense=False, two_streams=False):
         self.model = model
         self.dev = next(model.parameters()).device
         if self.dev.type != "cuda":
@@ -92,6 +92,10 @@ class TrainStep:
         self.lr_dev = torch.full((1,), self.lr, device=self.dev)
         self.step_dev = torch.zeros(1, device=self.dev, dtype=torch.int32)
         self.seed = 0x5DEECE66D
+        # optional: independent kernels of a step fork onto this stream (fork/join inside the library).
+        # Measured on MI355X at B = 4096: no gain eager, 12 % SLOWER under hipGraph replay (cross-stream
+        # edges cost more than the overlap of ~20 us kernels buys), hence off by default.
+        self.aux_stream = torch.cuda.Stream(device=self.dev) if two_streams else None
         self.rows_seen = 0
         # distributed
         if distributed is None:
@@ -120,7 +124,7 @@ class TrainStep:
         # d(mean over the GLOBAL batch)/dparams: each rank scales by 1/global_rows, the all-reduce SUMs
         N.train_fwd_bwd(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, B,
                         D.grad_scale(global_rows, Q), self.loss_sum, None, self.ws, st.flags,
-                        seed=self.seed, step_dev=self.step_dev)
+                        seed=self.seed, step_dev=self.step_dev, aux_stream=self.aux_stream)
         if self.distributed:
             D.allreduce_gradients(self.grad, self.pg)
         if self.grad_clip > 0:

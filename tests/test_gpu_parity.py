@@ -573,3 +573,62 @@ def test_step_indexed_equals_step():
     for other in res[1:]:
         assert abs(res[0][0] - other[0]) <= 1e-6 * abs(res[0][0])
         assert torch.allclose(res[0][1], other[1], rtol=1e-5, atol=1e-6)
+
+
+def test_c4_four_levels_window_vs_dense_and_oracle():
+    """BASELINE config C4 model (4 resolutions, 49 728 knots, D = 49 798): the window path walks more
+    than three levels; compare with the dense path and, for the prediction, with the float64 oracle."""
+    cfg = dict(p=0, k_spatial_centers=[1024, 4096, 16384, 28224], k_temporal_centers=[10, 15, 45],
+               hidden_dims=[256, 256, 128], layernorm=True, basis="wendland", output_dim=1, B=300, seed=61)
+    X, coords, t, y = cases.make_inputs(cfg)
+    d = dev()
+    outs = []
+    for dense in (False, True):
+        m = build_model(cfg)
+        m.force_dense_path = dense
+        m.train()
+        yp = m(*(torch.from_numpy(a).to(d) for a in (X, coords, t)))
+        torch.nn.MSELoss()(yp, torch.from_numpy(y).to(d)).backward()
+        outs.append((yp.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}))
+    (yw, gw), (yd, gd) = outs
+    assert np.abs(yw - yd).max() <= 2e-6 * max(1.0, np.abs(yd).max())
+    for k in gd:
+        assert rel_l2(gw[k], gd[k]) <= 2e-6, k
+    yo, _, _, _, _ = orc.model_forward(X, coords, t, cases.make_state(cfg), cfg)
+    assert np.abs(yw - yo).max() <= TOL * max(1.0, np.abs(yo).max())
+
+
+def test_predictor_large_grid_chunks():
+    """Dense-grid inference (config C5 shape, scaled): 200 000 points through 65 536-row chunks with a
+    ragged tail, window vs dense kernels."""
+    from stnf.engine import Predictor
+    cfg = cases.MODEL_CASES["c2_b257"]
+    d = dev()
+    m = build_model(cfg)
+    m.eval()
+    g = torch.Generator().manual_seed(3)
+    n = 200_000
+    coords = torch.rand(n, 2, generator=g).to(d)
+    t = (torch.randint(0, 100, (n,), generator=g).float() / 99.0).to(d)
+    a = Predictor(m, chunk=65536, use_graph=True).predict(coords, t)
+    b = Predictor(m, chunk=50000, use_graph=False, force_dense=True).predict(coords[:60000], t[:60000])
+    assert a.shape == (n, 1) and torch.isfinite(a).all()
+    assert torch.allclose(a[:60000], b, rtol=1e-5, atol=2e-6)
+
+
+def test_engine_two_streams_equals_one():
+    """The optional auxiliary stream (fork/join inside the library) must not change the numbers."""
+    from stnf.engine import TrainStep
+    cfg = cases.MODEL_CASES["c2_b257"]
+    d = dev()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    res = []
+    for two in (False, True):
+        m = build_model(cfg)
+        eng = TrainStep(m, ema_decay=0.99, max_batch=cfg["B"], two_streams=two)
+        for _ in range(3):
+            eng.step(None, coords, t, y)
+        torch.cuda.synchronize()
+        res.append((eng.mean_loss(), eng.flat.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])      # same kernels, same order of every sum
