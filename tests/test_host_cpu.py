@@ -187,3 +187,29 @@ def test_ema_and_metrics_host_logic():
     assert set(sd) == {"decay", "shadow"}
     mt = compute_metrics(np.array([1.0, 2.0, np.nan, 4.0]), np.array([1.5, 2.0, 3.0, 3.0]))
     assert abs(mt["mse"] - (0.25 + 0 + 1) / 3) < 1e-9 and set(mt) == {"rmse", "mae", "r2", "mse"}
+
+
+def test_device_dataset_matches_reference_sample_order():
+    """DeviceDataset.from_mask (vectorised) == the reference's create_dataset_from_mask semantics
+    (scripts/train_st_interp.py:413-450): argwhere order, NaN targets skipped, t = t_idx/(T-1)."""
+    from stnf.dataio import DeviceDataset
+    rs = np.random.RandomState(0)
+    T, S = 7, 11
+    z = rs.standard_normal((T, S)).astype(np.float32)
+    z[2, 3] = np.nan
+    coords = rs.uniform(0, 1, (S, 2)).astype(np.float32)
+    mask = rs.uniform(size=(T, S)) < 0.4
+    mask[2, 3] = True
+    ds = DeviceDataset.from_mask(z, coords, mask, device="cpu")
+    exp = []
+    for t_idx, s_idx in np.argwhere(mask):              # the reference's loop, restated
+        if np.isnan(z[t_idx, s_idx]):
+            continue
+        exp.append((coords[s_idx, 0], coords[s_idx, 1], np.float32(t_idx / (T - 1)), z[t_idx, s_idx]))
+    exp = np.array(exp, dtype=np.float32)
+    got = torch.cat([ds.coords, ds.t, ds.y], 1).numpy()
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    one = DeviceDataset.from_mask(z[:1], coords, mask[:1], device="cpu")
+    assert float(one.t.abs().max()) == 0.0               # T == 1 -> t = 0
+    parts = ds.epoch_batches(4, shuffle=False)
+    assert sum(p.numel() for p in parts) == len(ds) and parts[-1].numel() == len(ds) % 4 or len(ds) % 4 == 0
