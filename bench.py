@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dense", action="store_true", help="force the materialising (dense) kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the extra per-GPU batch sizes (N = 1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -293,6 +294,32 @@ def main():
             "nonzero_obs_knot_pairs_per_obs": nnz / B,
             "final_mean_loss": loss,
         }
+        if args.gpus == 1 and not args.no_sweep:
+            # the survey's per-GPU batch sweep: same model, same step, other batch sizes
+            sweep = {}
+            for b2 in (16384, 65536):
+                if b2 == B or b2 > n_obs:
+                    continue
+                torch.manual_seed(0)
+                m2 = STInterpMLP(p=0, k_spatial_centers=wl["k_spatial_centers"],
+                                 k_temporal_centers=wl["k_temporal_centers"], hidden_dims=wl["hidden_dims"],
+                                 dropout=args.dropout, layernorm=True).to(dev)
+                m2.train()
+                e2 = TrainStep(m2, lr=2e-2, weight_decay=5e-4, grad_clip=10.0, ema_decay=0.999, max_batch=b2,
+                               use_graph=not args.no_graph)
+                nb2 = max(n_obs // b2, 1)
+                for i in range(5):
+                    e2.step_indexed(coords, t, y, perm[(i % nb2) * b2:(i % nb2) * b2 + b2])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                k2 = 40
+                for i in range(k2):
+                    e2.step_indexed(coords, t, y, perm[(i % nb2) * b2:(i % nb2) * b2 + b2])
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                sweep[str(b2)] = {"obs_per_s": b2 * k2 / dt, "ms_per_step": dt / k2 * 1e3}
+                del e2, m2
+            out["batch_sweep"] = sweep
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, B, args.dropout)
         print(json.dumps(out))

@@ -252,7 +252,15 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceGroup grp) {
     const int c = (blk * 256 + threadIdx.x) * 4;
     if (c >= jb.n) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < jb.splits; ++s) {
+    int s = 0;
+    for (; s + 3 < jb.splits; s += 4) {           // 4 independent loads in flight
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(jb.src + (int64_t)(s + u) * jb.stride + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; s < jb.splits; ++s) {
       const float4 v = *reinterpret_cast<const float4 *>(jb.src + (int64_t)s * jb.stride + c);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
@@ -263,10 +271,14 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceGroup grp) {
   const int c = blk * 64 + tx;
   float s0 = 0.f, s1 = 0.f;
   if (c < jb.n) {
+    // 8 independent loads per pass (a loop of one load + add would wait on every load)
     int s = ty;
-    for (; s + 4 < jb.splits; s += 8) {
-      s0 += jb.src[(int64_t)s * jb.stride + c];
-      s1 += jb.src[(int64_t)(s + 4) * jb.stride + c];
+    for (; s + 28 < jb.splits; s += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = jb.src[(int64_t)(s + 4 * u) * jb.stride + c];
+      s0 += (v[0] + v[2]) + (v[4] + v[6]);
+      s1 += (v[1] + v[3]) + (v[5] + v[7]);
     }
     for (; s < jb.splits; s += 4) s0 += jb.src[(int64_t)s * jb.stride + c];
   }

@@ -84,6 +84,8 @@ template <int NI, int MT>
 __device__ __forceinline__ void gemm16_ni(f32x4 (*acc)[MAX_NI], const float *__restrict__ A, const float *__restrict__ Wn,
                                           int K, int wave, int c16, int q) {
   const int nchunk = (K + 31) >> 5;
+  // two 32-deep chunks in flight per wave (four measured no faster: the phase is paced by the shared
+  // MFMA pipe at 4 waves per SIMD, not by the load round trips)
   BFrag<NI> f0, f1;
   load_bfrag<NI>(f0, Wn, K, 0, wave, c16, q);
   for (int c = 0; c < nchunk; c += 2) {
@@ -155,11 +157,26 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   float *cur = act0, *nxt = act1;
   STAMP(1);
+  // output-layer weights of q = 0 (the MSE head has Q = 1): requested now, used at the very end
+  const int hl_head = a.n_layers ? a.L[a.n_layers - 1].h : a.h_in;
+  float wo0[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) wo0[cc] = a.Wo[min(lane + 64 * cc, hl_head - 1)];
+  const float bo0 = a.bo[0];
 
   for (int li = 0; li < a.n_layers; ++li) {
     const TailLayer &L = a.L[li];
     const int h = L.h, hp = L.hp;
     const int NT = h >> 4;
+    // LayerNorm parameters of this layer: requested before the GEMM, consumed after it (one L2 round
+    // trip hidden); clamped columns, no conditional loads
+    float gv[4], bev[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int colc = min(lane + 64 * cc, h - 1);
+      gv[cc] = a.layernorm ? L.g[colc] : 1.f;
+      bev[cc] = a.layernorm ? L.be[colc] : 0.f;
+    }
     f32x4 acc[MT][MAX_NI];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -182,15 +199,7 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
     }
     lds_barrier();
     STAMP(3 + 4 * li);
-    // LayerNorm -> ReLU -> Dropout, wave w owns rows RPW*w .. RPW*w+RPW-1.  gamma/beta are loaded once per
-    // layer from clamped columns (no conditional loads: each would cost its own L2 round trip).
-    float gv[4], bev[4];
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      const int colc = min(lane + 64 * cc, h - 1);
-      gv[cc] = a.layernorm ? L.g[colc] : 1.f;
-      bev[cc] = a.layernorm ? L.be[colc] : 0.f;
-    }
+    // LayerNorm -> ReLU -> Dropout, wave w owns rows RPW*w .. RPW*w+RPW-1
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = RPW * wave + rr;
@@ -249,10 +258,16 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
     const int grow = row0 + row;
     for (int qq = 0; qq < a.Q; ++qq) {
       float s = 0.f;
-      for (int col = lane; col < hl; col += 64) s = fmaf(cur[row * ACT_LD + col], a.Wo[qq * hl + col], s);
+      if (qq == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          if (lane + 64 * cc < hl) s = fmaf(cur[row * ACT_LD + lane + 64 * cc], wo0[cc], s);
+      } else {
+        for (int col = lane; col < hl; col += 64) s = fmaf(cur[row * ACT_LD + col], a.Wo[qq * hl + col], s);
+      }
       s = wave_sum(s);
       if (lane == 0 && grow < a.B) {
-        const float yv = s + a.bo[qq];
+        const float yv = s + (qq == 0 ? bo0 : a.bo[qq]);
         a.y_pred[(size_t)grow * a.Q + qq] = yv;
         if (a.y) {
           const float d = yv - a.y[(size_t)grow * a.Q + qq];

@@ -145,20 +145,31 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const float *__restrict
     if (b < B) { keys[b] = kk[i]; atomicAdd(&hist[kk[i]], 1); }
   }
   __syncthreads();
-  // exclusive scan: thread tid owns cells [tid*per, tid*per+per)
+  // exclusive scan: thread tid owns cells [tid*per, tid*per+per); wave-level shuffles, two barriers
   const int per = (ncell + 1023) / 1024;
   const int i0 = tid * per, i1 = min(i0 + per, ncell);
   int s = 0;
   for (int i = i0; i < i1; ++i) s += hist[i];
-  part[tid] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    int v = tid >= o ? part[tid - o] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6;
+  int incl = s;                                  // inclusive scan inside the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
   }
-  int run = part[tid] - s;
+  if (lane == 63) part[wv] = incl;               // wave totals
+  __syncthreads();
+  if (tid < 16) {                                // 16 waves: scan their totals in one wave
+    int tot = part[tid];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int v = __shfl_up(tot, o, 64);
+      if (tid >= o) tot += v;
+    }
+    part[16 + tid] = tot;                        // inclusive totals
+  }
+  __syncthreads();
+  int run = incl - s + (wv > 0 ? part[16 + wv - 1] : 0);
   for (int i = i0; i < i1; ++i) {
     const int cnt = hist[i];
     start[i] = run;
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const float *__restrict
     hist[i] = run;            // cursor for the scatter
     run += cnt;
   }
-  if (tid == 1023) { start[ncell] = part[1023]; cell_start[ncell] = part[1023]; }
+  if (tid == 1023) { start[ncell] = part[31]; cell_start[ncell] = part[31]; }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < PER_T; ++i) {
