@@ -44,6 +44,36 @@ MODEL_CASES = {
                          output_dim=1, B=257, seed=18),
 }
 
+# N3 cases: quantile / multi-quantile objectives and the delta head, on top of the
+# model cases above.  `loss`: taus, prediction-level non-crossing (nc_weight, nc_power), or the
+# delta-reparameterised head with the parameter-level penalty (delta, nc_lambda).
+TAUS5 = [0.05, 0.25, 0.5, 0.75, 0.95]
+QUANTILE_CASES = {
+    "tiny9_q90": dict(base="tiny9", output_dim=1, seed=31, loss=dict(taus=[0.9])),
+    "tiny9_mq5_nc1": dict(base="tiny9", output_dim=5, seed=32,
+                          loss=dict(taus=TAUS5, nc_weight=0.5, nc_power=1)),
+    "tiny9_mq5_nc2": dict(base="tiny9_ln_p3", output_dim=5, seed=33,
+                          loss=dict(taus=TAUS5, nc_weight=2.0, nc_power=2)),
+    "tiny9_delta5": dict(base="tiny9", output_dim=5, seed=34,
+                         loss=dict(taus=TAUS5, delta=True, nc_lambda=0.1)),
+    "default227_q10": dict(base="default227", output_dim=1, seed=35, loss=dict(taus=[0.1])),
+    "default227_mq5": dict(base="default227", output_dim=5, seed=36,
+                           loss=dict(taus=TAUS5, nc_weight=0.5, nc_power=1)),
+    "default227_delta5": dict(base="default227", output_dim=5, seed=37,
+                              loss=dict(taus=TAUS5, delta=True, nc_lambda=0.05)),
+    "c2_b257_mq3": dict(base="c2_b257", output_dim=3, seed=38,
+                        loss=dict(taus=[0.1, 0.5, 0.9], nc_weight=1.0, nc_power=2)),
+}
+
+
+def quantile_cfg(name):
+    """Model config of a QUANTILE_CASES entry (base case + overrides) and its loss spec."""
+    q = QUANTILE_CASES[name]
+    cfg = dict(MODEL_CASES[q["base"]])
+    cfg.update(output_dim=q["output_dim"], seed=q["seed"], delta=bool(q["loss"].get("delta")))
+    return cfg, q["loss"]
+
+
 # Cases small enough that the fp32 reference arrays are stored next to the float64 truth.
 FULL_CASES = ["tiny9", "tiny9_ln_p3"]
 # Tensors with more elements than this are stored as digests (samples + row/col sums + norm).
@@ -94,6 +124,12 @@ def state_layout(cfg):
             idx += 1
         idx += 1  # ReLU
         prev = h
+    if cfg.get("delta"):
+        # st_interp.py:671-686: shared trunk + one (d+1,) delta vector per quantile
+        out = [(k.replace("mlp.", "mlp_trunk."), shp, kind) for k, shp, kind in out]
+        for k in range(cfg["output_dim"]):
+            out.append((f"delta_params.{k}", (prev + 1,), "delta"))
+        return out
     out.append((f"mlp.{idx}.weight", (cfg["output_dim"], prev), "lin_w"))
     out.append((f"mlp.{idx}.bias", (cfg["output_dim"],), "lin_b"))
     return out
@@ -114,6 +150,11 @@ def make_state(cfg):
         elif kind == "lin_b":
             b = 1.0 / math.sqrt(fan_in)
             st[key] = rs.uniform(-b, b, size=shape).astype(np.float32)
+        elif kind == "delta":
+            # mixed signs so that both branches of J(delta_k) and of the check loss are exercised
+            v = 0.05 * rs.standard_normal(shape)
+            v[0] = 0.15 * rs.standard_normal()
+            st[key] = v.astype(np.float32)
         elif kind == "ln_g":
             st[key] = (1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32)
         else:

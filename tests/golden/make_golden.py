@@ -90,10 +90,11 @@ def build(cfg):
                         k_temporal_centers=cfg["k_temporal_centers"],
                         hidden_dims=cfg["hidden_dims"], dropout=0.0, layernorm=cfg["layernorm"],
                         spatial_learnable=False, spatial_init_method="uniform",
-                        spatial_basis_function=cfg["basis"], output_dim=cfg["output_dim"])
+                        spatial_basis_function=cfg["basis"], output_dim=cfg["output_dim"],
+                        use_delta_reparameterization=bool(cfg.get("delta")))
     st = cases.make_state(cfg)
     sd = model.state_dict()
-    keys = [k for k in sd if k.startswith("mlp.")]
+    keys = [k for k in sd if k.startswith(("mlp.", "mlp_trunk.", "delta_params."))]
     assert sorted(keys) == sorted(st.keys()), (keys, list(st))
     for k, v in st.items():
         assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
@@ -192,7 +193,137 @@ def gen_case(name):
           f"phi_err32d={out['phi_err32d_maxabs']:.2e} y_err32={out['y_err32_maxabs']:.2e}")
 
 
+# ---------------------------------------------------------------------------------------------
+# N3: quantile objectives + delta head, driven exactly as the batch body does
+# (train_st_interp.py:617-658) with the reference's own loss functions
+# ---------------------------------------------------------------------------------------------
+def n3_loss(model, yp, y, lc):
+    taus = lc["taus"]
+    if len(taus) == 1:
+        return ref_train.quantile_loss(yp, y, taus[0])
+    losses = [ref_train.quantile_loss(yp[:, i:i + 1], y, q) for i, q in enumerate(taus)]
+    loss = torch.mean(torch.stack(losses))
+    if lc.get("delta"):
+        if lc.get("nc_lambda", 0.0) > 0:
+            loss = loss + lc["nc_lambda"] * ref_train.compute_p_nc_delta_penalty(
+                model.get_delta_parameters())
+    elif lc.get("nc_weight", 0.0) > 0:
+        loss = loss + lc["nc_weight"] * ref_train.non_crossing_penalty(
+            yp, reduction="mean", power=int(lc.get("nc_power", 1)))
+    return loss
+
+
+def n3_run(model, X, coords, t, y, lc):
+    model.train()
+    model.zero_grad()
+    yp = model(X, coords, t)
+    loss = n3_loss(model, yp, y, lc)
+    loss.backward()
+    return yp.detach(), loss.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+
+def n3_opt(model, X, coords, t, y, lc):
+    o = cases.OPT
+    opt = torch.optim.AdamW(model.parameters(), lr=o["lr"], weight_decay=o["weight_decay"],
+                            betas=o["betas"], eps=o["eps"])
+    ema = ModelEMA(model, decay=o["ema_decay"])
+    losses = []
+    model.train()
+    for _ in range(o["steps"]):
+        opt.zero_grad()
+        loss = n3_loss(model, model(X, coords, t), y, lc)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), o["grad_clip"])
+        opt.step()
+        ema.update(model)
+        losses.append(float(loss))
+    return ({n: p.detach().clone() for n, p in model.named_parameters()},
+            {n: v.detach().clone() for n, v in ema.shadow.items()}, np.array(losses, dtype=np.float64))
+
+
+def gen_quantile_case(name):
+    cfg, lc = cases.quantile_cfg(name)
+    X, coords, t, y = (torch.from_numpy(a) for a in cases.make_inputs(cfg))
+    d = (X.double(), coords.double(), t.double(), y.double())
+    out = {}
+    y32, l32, g32 = n3_run(build(cfg), X, coords, t, y, lc)
+    y64, l64, g64 = n3_run(build(cfg).double(), *d, lc)
+    out["y32"], out["y64"] = y32.numpy(), y64.numpy()
+    out["loss32"], out["loss64"] = np.float32(l32.item()), np.float64(l64.item())
+    # the pieces of the objective on the float64 predictions, from the reference's own functions
+    out["check64"] = np.array([float(ref_train.quantile_loss(y64[:, i:i + 1], d[3], q))
+                               for i, q in enumerate(lc["taus"])])
+    out["nc1_64"] = np.float64(ref_train.non_crossing_penalty(y64, "mean", 1).item())
+    out["nc2_64"] = np.float64(ref_train.non_crossing_penalty(y64, "mean", 2).item())
+    out["crps64"] = np.float64(ref_train.compute_crps_multi_quantile(
+        y64.numpy(), d[3].numpy(), lc["taus"]))
+    out["crossing_rows"] = np.int64(((y64[:, :-1] - y64[:, 1:]) > 0).any(1).sum().item()
+                                    if y64.shape[1] > 1 else 0)
+    for k in g64:
+        store(out, "g", k, g64[k].numpy(), g32[k].numpy(), cfg["seed"] + 7, False)
+    p32, s32, ls32 = n3_opt(build(cfg), X, coords, t, y, lc)
+    p64, s64, ls64 = n3_opt(build(cfg).double(), *d, lc)
+    out["opt_losses32"], out["opt_losses64"] = ls32, ls64
+    for k in p64:
+        store(out, "p", k, p64[k].numpy(), p32[k].numpy(), cfg["seed"] + 7, False)
+        store(out, "ema", k, s64[k].numpy(), s32[k].numpy(), cfg["seed"] + 7, False)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB  loss64={out['loss64']:.6f} "
+          f"crossing_rows={int(out['crossing_rows'])}")
+
+
+def gen_n3_known_answers():
+    """Known answers of the loss / penalty / CRPS functions on fixed inputs: the vectors of the
+    reference's own tests (tests/stnf/models/test_crps_eq_4_6.py, test_p_nc_delta_penalty.py) plus
+    seeded random ones, evaluated by the reference's functions."""
+    out = {}
+    rs = np.random.RandomState(77)
+    yp = rs.standard_normal((64, 5))
+    y = rs.standard_normal((64, 1))
+    out["ka_yp"], out["ka_y"] = yp, y
+    for i, q in enumerate(cases.TAUS5):
+        out[f"ka_check_{i}"] = np.float64(ref_train.check_loss_numpy(yp[:, i], y[:, 0], q))
+        out[f"ka_qloss_{i}"] = np.float64(ref_train.quantile_loss(
+            torch.from_numpy(yp[:, i:i + 1]), torch.from_numpy(y), q).item())
+    out["ka_nc1"] = np.float64(ref_train.non_crossing_penalty(torch.from_numpy(yp), "mean", 1).item())
+    out["ka_nc2_sum"] = np.float64(ref_train.non_crossing_penalty(torch.from_numpy(yp), "sum", 2).item())
+    out["ka_crps"] = np.float64(ref_train.compute_crps_multi_quantile(yp, y, cases.TAUS5))
+    out["ka_crps_w"] = np.float64(ref_train.compute_crps_multi_quantile(
+        yp, y, cases.TAUS5, weights=np.array([1.0, 2.0, 3.0, 2.0, 1.0])))
+    # test_crps_eq_4_6.py vectors
+    yt = np.array([2.0, 3.0, 4.0, 5.0])
+    pd = {0.05: yt - 1.0, 0.25: yt - 0.5, 0.5: yt.copy(), 0.75: yt + 0.5, 0.95: yt + 1.0}
+    out["ka_crps_thesis"] = np.float64(ref_train.compute_crps(pd, yt))
+    out["ka_crps_single"] = np.float64(ref_train.compute_crps({0.5: np.array([2.5])}, np.array([2.0])))
+    # P_nc(delta): the worked example of test_p_nc_delta_penalty.py + random + tie rows
+    delta = rs.standard_normal((5, 9)) * 0.5
+    delta[2, 0] = 5.0                                    # J = 0 branch
+    delta[3, 1:] = np.abs(delta[3, 1:]); delta[3, 0] = 0.0   # tie: S == d_k0 == 0
+    delta[4, 3] = 0.0                                    # clamp boundary
+    ps = [torch.nn.Parameter(torch.from_numpy(delta[k].copy())) for k in range(5)]
+    P = ref_train.compute_p_nc_delta_penalty(ps)
+    P.backward()
+    out["ka_delta"] = delta
+    out["ka_pnc"] = np.float64(P.item())
+    out["ka_pnc_grad"] = np.stack([p.grad.numpy() if p.grad is not None else np.zeros(9) for p in ps])
+    ex = [torch.nn.Parameter(torch.tensor([0.3, 0.1, 0.2, 0.3, 0.4], dtype=torch.float64)),
+          torch.nn.Parameter(torch.tensor([2.0, 1.0, -0.5, 0.3, -0.2], dtype=torch.float64)),
+          torch.nn.Parameter(torch.tensor([0.1, 1.0, -0.5, 0.3, -0.2], dtype=torch.float64))]
+    out["ka_pnc_example"] = np.float64(ref_train.compute_p_nc_delta_penalty(ex).item())
+    np.savez_compressed(os.path.join(HERE, "n3_known_answers.npz"), **out)
+    print("n3_known_answers.npz", len(out), "arrays; P_nc =", out["ka_pnc"])
+
+
 if __name__ == "__main__":
-    gen_knots()
-    for nm in cases.MODEL_CASES:
-        gen_case(nm)
+    which = sys.argv[1:] or ["knots", "model", "n3"]
+    if "knots" in which:
+        gen_knots()
+    if "model" in which:
+        for nm in cases.MODEL_CASES:
+            gen_case(nm)
+    if "n3" in which:
+        import scripts.train_st_interp as ref_train  # noqa: E402  (the reference's loss functions)
+        gen_n3_known_answers()
+        for nm in cases.QUANTILE_CASES:
+            gen_quantile_case(nm)

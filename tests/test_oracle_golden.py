@@ -174,3 +174,97 @@ def test_torch_port_matches_reference_fp32(name):
             ref = g[f"g64/{k}"]
             err = np.abs(pten.grad.numpy() - ref).max()
             assert err <= max(2 * float(g[f"gerr32_maxabs/{k}"]), 1e-6 * np.abs(ref).max() + 1e-9), k
+
+
+# ------------------------------------------------------------------ N3 quantile objectives, delta head, CRPS
+def test_n3_known_answers():
+    """check loss / non-crossing / CRPS / P_nc(delta) against values the reference's own functions
+    produced (incl. the vectors of its tests test_crps_eq_4_6.py, test_p_nc_delta_penalty.py)."""
+    g = load("n3_known_answers")
+    yp, y = g["ka_yp"], g["ka_y"]
+    for i, q in enumerate(cases.TAUS5):
+        assert abs(orc.check_loss(yp[:, i:i + 1], y, q) - float(g[f"ka_check_{i}"])) < 1e-15
+        assert abs(orc.check_loss(yp[:, i:i + 1], y, q) - float(g[f"ka_qloss_{i}"])) < 1e-15
+    assert abs(orc.non_crossing_penalty(yp, 1, "mean") - float(g["ka_nc1"])) < 1e-14
+    assert abs(orc.non_crossing_penalty(yp, 2, "sum") - float(g["ka_nc2_sum"])) < 1e-12
+    assert orc.non_crossing_penalty(yp[:, :1]) == 0.0
+    assert abs(orc.crps(yp, y, cases.TAUS5) - float(g["ka_crps"])) < 1e-14
+    assert abs(orc.crps(yp, y, cases.TAUS5, [1, 2, 3, 2, 1]) - float(g["ka_crps_w"])) < 1e-14
+    yt = np.array([2.0, 3.0, 4.0, 5.0])
+    preds = np.stack([yt - 1.0, yt - 0.5, yt, yt + 0.5, yt + 1.0], axis=1)
+    assert abs(orc.crps(preds, yt, cases.TAUS5) - float(g["ka_crps_thesis"])) < 1e-15
+    assert abs(orc.crps(np.array([[2.5]]), np.array([2.0]), [0.5]) - float(g["ka_crps_single"])) < 1e-15
+    # reference test vectors: check loss 0.25 / 0.05 for e = 0.5 at tau 0.5 / 0.1
+    assert abs(orc.check_loss(np.array([1.0, 2.0, 3.0]), np.array([1.5, 2.5, 3.5]), 0.5) - 0.25) < 1e-15
+    assert abs(orc.check_loss(np.array([1.0, 2.0, 3.0]), np.array([1.5, 2.5, 3.5]), 0.1) - 0.05) < 1e-15
+    P, gP = orc.p_nc_delta(g["ka_delta"])
+    assert abs(P - float(g["ka_pnc"])) < 1e-14
+    assert np.abs(gP - g["ka_pnc_grad"]).max() < 1e-15     # incl. the tie and clamp-boundary rows
+    ex = np.array([[0.3, 0.1, 0.2, 0.3, 0.4], [2.0, 1.0, -0.5, 0.3, -0.2], [0.1, 1.0, -0.5, 0.3, -0.2]])
+    Pe, _ = orc.p_nc_delta(ex)
+    assert abs(Pe - float(g["ka_pnc_example"])) < 1e-15 and abs(Pe - (0.1 - 0.7)) < 1e-15
+    assert orc.p_nc_delta(ex[:1])[0] == 0.0
+
+
+def test_n3_objective_gradient_is_the_derivative():
+    """Finite differences of quantile_objective / p_nc_delta away from the kinks."""
+    rs = np.random.RandomState(5)
+    yp, y = rs.standard_normal((9, 4)), rs.standard_normal((9, 1))
+    taus = [0.1, 0.4, 0.6, 0.9]
+    for pw in (1, 2):
+        L0, dY = orc.quantile_objective(yp, y, taus, 0.7, pw)
+        for (b, q) in [(0, 0), (3, 2), (8, 3)]:
+            e = np.zeros_like(yp); e[b, q] = 1e-7
+            L1, _ = orc.quantile_objective(yp + e, y, taus, 0.7, pw)
+            assert abs((L1 - L0) / 1e-7 - dY[b, q]) < 1e-5
+    d = rs.standard_normal((4, 6))
+    P0, gP = orc.p_nc_delta(d)
+    for (k, j) in [(1, 0), (2, 3), (3, 5), (0, 2)]:
+        e = np.zeros_like(d); e[k, j] = 1e-7
+        assert abs((orc.p_nc_delta(d + e)[0] - P0) / 1e-7 - gP[k, j]) < 1e-6
+    dW, db = rs.standard_normal((4, 5)), rs.standard_normal(4)
+    Wo, bo = orc.delta_head(d)
+    # <delta_head(d), (dW,db)> == <d, delta_head_backward(dW,db)>  (adjoint)
+    assert abs((Wo * dW).sum() + (bo * db).sum() - (d * orc.delta_head_backward(dW, db)).sum()) < 1e-12
+
+
+@pytest.mark.parametrize("name", list(cases.QUANTILE_CASES))
+def test_n3_oracle_matches_reference_float64(name):
+    cfg, lc = cases.quantile_cfg(name)
+    g = load(name)
+    X, coords, t, y = cases.make_inputs(cfg)
+    params = cases.make_state(cfg)
+    yp, loss, grads = orc.quantile_step_grads(X, coords, t, y, params, cfg, lc)
+    assert yp.shape == (cfg["B"], cfg["output_dim"])
+    assert np.abs(yp - g["y64"]).max() < 1e-11
+    assert abs(loss - float(g["loss64"])) < 1e-12
+    for i, q in enumerate(lc["taus"]):
+        assert abs(orc.check_loss(yp[:, i:i + 1], y, q) - g["check64"][i]) < 1e-12
+    assert abs(orc.non_crossing_penalty(yp, 1) - float(g["nc1_64"])) < 1e-12
+    assert abs(orc.non_crossing_penalty(yp, 2) - float(g["nc2_64"])) < 1e-12
+    assert abs(orc.crps(yp, y, lc["taus"]) - float(g["crps64"])) < 1e-12
+    assert set(grads) == set(params)
+    for k in params:
+        _digest_check(grads[k], g, "g", k, cfg["seed"] + 7, 1e-10)
+
+
+@pytest.mark.parametrize("name", list(cases.QUANTILE_CASES))
+def test_n3_oracle_optimizer_steps(name):
+    cfg, lc = cases.quantile_cfg(name)
+    g = load(name)
+    o = cases.OPT
+    X, coords, t, y = cases.make_inputs(cfg)
+    params = {k: v.astype(np.float64) for k, v in cases.make_state(cfg).items()}
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v2 = {k: np.zeros_like(v) for k, v in params.items()}
+    shadow = {k: v.copy() for k, v in params.items()}
+    losses = []
+    for s in range(1, o["steps"] + 1):
+        _, loss, grads = orc.quantile_step_grads(X, coords, t, y, params, cfg, lc)
+        losses.append(loss)
+        orc.adamw_ema_step(params, grads, m, v2, shadow, s, o["lr"], o["weight_decay"], o["betas"],
+                           o["eps"], o["grad_clip"], o["ema_decay"])
+    assert np.abs(np.array(losses) - g["opt_losses64"]).max() < 1e-9
+    for k in params:
+        _digest_check(params[k], g, "p", k, cfg["seed"] + 7, 1e-8)
+        _digest_check(shadow[k], g, "ema", k, cfg["seed"] + 7, 1e-8)
