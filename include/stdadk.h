@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STDADK_ABI_VERSION 2
+#define STDADK_ABI_VERSION 3
 #define STDADK_MAX_HIDDEN 8
 #define STDADK_MAX_LEVELS 8
 #define STDADK_SUMSQ_PARTS 256 /* partial sums written by stdadk_sumsq_f32 */
@@ -114,6 +114,48 @@ int stdadk_mlp_backward_f32(const stdadk_mlp_desc *desc, const stdadk_mlp_tensor
  * n = B*Q elements.  dY may be NULL (evaluation); loss_sum may be NULL. */
 int stdadk_mse_f32(const float *y_pred, const float *y, int64_t n, float grad_scale, float *dY,
                    float *loss_sum, stdadk_stream_t stream);
+
+/* N3  quantile / multi-quantile objectives (scripts/train_st_interp.py:37-88,622-658) fused with
+ * their gradient, as a generalisation of stdadk_mse_f32.  For y_pred [B,Q] and y [B,y_cols]:
+ *   STDADK_LOSS_MSE     : sum (y_pred - y)^2
+ *   STDADK_LOSS_PINBALL : sum_q sum_b max((tau_q-1) e, tau_q e), e = y - y_pred   (quantile_loss, :37-50;
+ *                         the multi-quantile mean over q of per-quantile means, :625-632, is this sum
+ *                         divided by B*Q), plus the prediction-level non-crossing penalty
+ *                         nc_weight * mean_b sum_k relu(y_pred[b,k] - y_pred[b,k+1])^nc_power
+ *                         (non_crossing_penalty, :53-88, reduction "mean"; added as nc_weight*Q*sum so
+ *                         that loss_sum / (B*Q) is the reference's batch loss).
+ *   loss_sum[0] += that sum;   dY = grad_scale * d(sum)/dy_pred     (grad_scale = 1/(B*Q) for the mean)
+ * Sub-gradients follow torch: max() splits ties 1/2:1/2, relu'(0) = 0.  y_cols == 1 broadcasts one
+ * target over the Q outputs (the (B,1) targets of multi-quantile training). */
+#define STDADK_LOSS_MSE 0
+#define STDADK_LOSS_PINBALL 1
+#define STDADK_MAX_Q 8
+typedef struct stdadk_loss_desc {
+  int32_t kind;             /* STDADK_LOSS_*                                                    */
+  int32_t y_cols;           /* columns of y: Q, or 1 (broadcast)                                */
+  float tau[STDADK_MAX_Q];  /* quantile levels of the Q outputs (PINBALL)                       */
+  float nc_weight;          /* prediction-level non-crossing weight, 0 = off (PINBALL, Q > 1)   */
+  int32_t nc_power;         /* 1 (hinge) or 2 (squared hinge)                                   */
+} stdadk_loss_desc;
+int stdadk_loss_f32(const stdadk_loss_desc *loss, const float *y_pred, const float *y, int64_t B,
+                    int32_t Q, float grad_scale, float *dY, float *loss_sum, stdadk_stream_t stream);
+
+/* N3  delta-reparameterised output head (stnf/models/st_interp.py:671-686,849-877): the Q output
+ * rows are cumulative sums of per-quantile vectors delta_k = (delta_k0 | delta_k1..d),
+ *   beta_k = sum_{l<=k} delta_l,   Wo[k,:] = beta_k[1:],  bo[k] = beta_k[0],
+ * so the step-level entry points run unchanged on (Wo, bo).  delta is [Q, ldd] (ldd >= d+1).
+ * stdadk_delta_head_f32 builds Wo [Q,d] and bo [Q]; stdadk_delta_head_backward_f32 maps (dWo, dbo)
+ * back, d_delta_l = sum_{k>=l} d beta_k (overwrite), and adds the parameter-level penalty of
+ * compute_p_nc_delta_penalty (scripts/train_st_interp.py:91-160, used at :640-649):
+ *   P = sum_{k>=2} (delta_k0 - max(delta_k0, S_k)),  S_k = sum_j max(0, -delta_kj)
+ *   d_delta += lambda_grad * dP/d delta;   loss_sum[0] += lambda_loss * P   (loss_sum may be NULL)
+ * with torch's sub-gradients (max ties 1/2:1/2, clamp(min=0) passes the gradient at 0). */
+int stdadk_delta_head_f32(const float *delta, int64_t ldd, int32_t Q, int32_t d, float *Wo,
+                          float *bo, stdadk_stream_t stream);
+int stdadk_delta_head_backward_f32(const float *delta, const float *dWo, const float *dbo,
+                                   int64_t ldd, int32_t Q, int32_t d, float lambda_grad,
+                                   float lambda_loss, float *d_delta, float *loss_sum,
+                                   stdadk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A9  clip_grad_norm_ + AdamW + EMA on flat fp32 buffers of n elements
@@ -202,19 +244,21 @@ int stdadk_backward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *m
                         const float *dY, void *workspace, size_t workspace_bytes, uint64_t drop_seed,
                         const int32_t *step_dev, int32_t flags, stdadk_stream_t stream);
 
-/* A2-A8 in one call: training forward, nn.MSELoss and its gradient, backward:
- *   loss_sum[0] += sum((y_pred-y)^2);  grads = d/dparams of grad_scale * sum((y_pred-y)^2)
+/* A2-A8 in one call: training forward, the batch objective and its gradient, backward:
+ *   loss == NULL (nn.MSELoss): loss_sum[0] += sum((y_pred-y)^2), grads = d/dparams of
+ *   grad_scale * sum((y_pred-y)^2), y [B,Q];
+ *   loss != NULL: the objective of stdadk_loss_f32 (N3), y [B, loss->y_cols].
  * (grad_scale = 1/(rows*Q) of the GLOBAL batch, so summing the ranks' gradients gives the global
- * mean).  y [B,Q]; y_pred [B,Q] (caller's row order) is optional: NULL skips writing it.
+ * mean.)  y_pred [B,Q] (caller's row order) is optional: NULL skips writing it.
  * aux_stream (optional, NULL = none): a second stream onto which independent kernels of the step
  * are forked (event fork/join, capturable); on return every kernel has been joined into `stream`. */
 int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
                              const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,
                              const float *coords, const float *t, const float *X, const float *y,
-                             int64_t B, float grad_scale, float *loss_sum, float *y_pred,
-                             void *workspace, size_t workspace_bytes, uint64_t drop_seed,
-                             const int32_t *step_dev, int32_t flags, stdadk_stream_t stream,
-                             stdadk_stream_t aux_stream);
+                             int64_t B, float grad_scale, const stdadk_loss_desc *loss,
+                             float *loss_sum, float *y_pred, void *workspace, size_t workspace_bytes,
+                             uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
+                             stdadk_stream_t stream, stdadk_stream_t aux_stream);
 
 /* A0  batch producer (scripts/train_st_interp.py:413-460 dataset + collate, :609-612 H2D): rows
  * idx[b] (int64) of the device-resident observation arrays into contiguous batch buffers, one launch.

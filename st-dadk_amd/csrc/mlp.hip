@@ -470,6 +470,7 @@ struct Ctx {
   float *mse_dY = nullptr;
   float *mse_loss = nullptr;
   bool mse_done = false;        // set by run_forward when the loss was fused into the tail kernel
+  LossDev loss = {STDADK_LOSS_MSE, 0, {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f}, 0.f, 1};   // y_cols 0 = Q
   const float *dz0 = nullptr;   // set by run_backward: dZ of layer 0
   // optional second stream: independent kernels of a step fork onto it (hipGraph-capturable
   // fork/join through events); NULL = everything on `st`
@@ -595,6 +596,8 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
     a.Wo = P->W[L]; a.bo = P->b[L]; a.Q = Q;
     a.y_pred = y_pred;
     a.y = c.mse_y; a.grad_scale = c.mse_scale; a.dY = c.mse_dY; a.loss_sum = c.mse_loss;
+    a.loss = c.loss;
+    if (a.loss.y_cols == 0) a.loss.y_cols = Q;
     a.layernorm = d->layernorm; a.eps = d->ln_eps; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
     c.mse_done = c.mse_y != nullptr;
     { const char *e = getenv("STDADK_TAIL_STAMPS"); a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
@@ -856,7 +859,7 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
                                  const float *X, const float *y) {
   const Plan &pl = c.pl;
   BinBuffers bb = plan_bins(c.ws, pl);
-  int rc = bin_obs(coords, t, y, c.d->out_dim, X, b->p, (int)c.B, pl.G, bb, c.st);
+  int rc = bin_obs(coords, t, y, c.loss.y_cols ? c.loss.y_cols : c.d->out_dim, X, b->p, (int)c.B, pl.G, bb, c.st);
   if (rc) return rc;
   L1FwdArgs a;
   a.g = make_grid(b);
@@ -1092,7 +1095,8 @@ extern "C" int stdadk_backward_f32(const stdadk_basis_desc *b, const stdadk_mlp_
 extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
                                         const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
                                         const float *coords, const float *t, const float *X,
-                                        const float *y, int64_t B, float grad_scale, float *loss_sum,
+                                        const float *y, int64_t B, float grad_scale,
+                                        const stdadk_loss_desc *loss, float *loss_sum,
                                         float *y_pred, void *workspace, size_t workspace_bytes,
                                         uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
                                         stdadk_stream_t stream, stdadk_stream_t aux_stream) {
@@ -1105,6 +1109,9 @@ extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk
   c.aux = (aux_stream && aux_stream != stream) ? (hipStream_t)aux_stream : nullptr;
   STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "train_fwd_bwd: X is NULL with p=%d", b->p);
   c.P = P; c.G = G; c.st = (hipStream_t)stream; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = step_dev;
+  rc = make_loss(loss, d->out_dim, &c.loss);
+  if (rc) return rc;
+  const bool plain = loss_is_plain_mse(c.loss, d->out_dim);
   const int64_t n = B * d->out_dim;
   c.mse_scale = grad_scale; c.mse_dY = c.ws + c.pl.dY; c.mse_loss = loss_sum;
   if (window && c.aux && tail_enabled() && d->n_hidden > 1 && tail_supported(d, 1)) {
@@ -1126,7 +1133,9 @@ extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk
     rc = step_forward(c, b, true, coords, t, X, y, y_pred, stream);
     if (rc) return rc;
     if (!c.mse_done) {
-      rc = launch_mse(c.ws + c.pl.ypred, c.ws + c.pl.y_s, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
+      rc = plain ? launch_mse(c.ws + c.pl.ypred, c.ws + c.pl.y_s, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st)
+                 : launch_loss(c.loss, c.ws + c.pl.ypred, c.ws + c.pl.y_s, B, d->out_dim, grad_scale,
+                               c.ws + c.pl.dY, loss_sum, c.st);
       if (rc) return rc;
     }
     return step_backward(c, b, true, c.ws + c.pl.dY, true);
@@ -1136,7 +1145,8 @@ extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk
   rc = step_forward(c, b, false, coords, t, X, nullptr, yp, stream);
   if (rc) return rc;
   if (!c.mse_done) {
-    rc = launch_mse(yp, y, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
+    rc = plain ? launch_mse(yp, y, n, grad_scale, c.ws + c.pl.dY, loss_sum, c.st)
+               : launch_loss(c.loss, yp, y, B, d->out_dim, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
     if (rc) return rc;
   }
   return step_backward(c, b, false, c.ws + c.pl.dY, false);

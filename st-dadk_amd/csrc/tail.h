@@ -4,6 +4,7 @@
 // activations in LDS and the weights streamed from L2 in 32-deep K chunks onto the matrix cores.
 #pragma once
 #include "common.h"
+#include "loss.h"
 
 namespace stdadk {
 
@@ -34,10 +35,11 @@ struct TailFwdArgs {
   const float *Wo, *bo;         // output layer [Q][h_last], [Q]
   int Q;
   float *y_pred;                // [B][Q]
-  const float *y;               // targets in the same row order, or NULL (no loss)
+  const float *y;               // targets [B][loss.y_cols] in the same row order, or NULL (no loss)
+  LossDev loss;                 // objective evaluated on (y_pred, y)
   float grad_scale;
-  float *dY;                    // [B][Q] = 2 (y_pred - y) grad_scale, or NULL
-  float *loss_sum;              // += sum (y_pred - y)^2, or NULL
+  float *dY;                    // [B][Q] = grad_scale * d(loss sum)/dy_pred, or NULL
+  float *loss_sum;              // += the loss sum of this launch's rows, or NULL
   int layernorm;
   float eps, drop_p;
   uint64_t seed;

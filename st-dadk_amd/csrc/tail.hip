@@ -249,13 +249,15 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
 
-  // output layer (+ MSE): y[row][qq] = a_last[row,:] . Wo[qq,:] + bo[qq]
+  // output layer (+ loss): y[row][qq] = a_last[row,:] . Wo[qq,:] + bo[qq]
   const int hl = a.n_layers ? a.L[a.n_layers - 1].h : a.h_in;
   float lsum = 0.f;
+  const bool plain_mse = a.loss.kind == STDADK_LOSS_MSE && a.loss.y_cols == a.Q;
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = RPW * wave + rr;
     const int grow = row0 + row;
+    float mine = 0.f;              // lane q keeps prediction q of this row (general objectives)
     for (int qq = 0; qq < a.Q; ++qq) {
       float s = 0.f;
       if (qq == 0) {
@@ -266,19 +268,32 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
         for (int col = lane; col < hl; col += 64) s = fmaf(cur[row * ACT_LD + col], a.Wo[qq * hl + col], s);
       }
       s = wave_sum(s);
+      const float yv = s + (qq == 0 ? bo0 : a.bo[qq]);
+      mine = lane == qq ? yv : mine;
       if (lane == 0 && grow < a.B) {
-        const float yv = s + (qq == 0 ? bo0 : a.bo[qq]);
         a.y_pred[(size_t)grow * a.Q + qq] = yv;
-        if (a.y) {
+        if (a.y && plain_mse) {
           const float d = yv - a.y[(size_t)grow * a.Q + qq];
           lsum = fmaf(d, d, lsum);
           if (a.dY) a.dY[(size_t)grow * a.Q + qq] = 2.0f * d * a.grad_scale;
         }
       }
     }
+    if (a.y && !plain_mse) {
+      // check loss / non-crossing / broadcast targets: lane q owns element (row, q)
+      const float yup = __shfl(mine, lane + 1, 64);
+      const float ydn = __shfl(mine, lane - 1, 64);
+      if (lane < a.Q && grow < a.B) {
+        const float yt = a.y[(size_t)grow * a.loss.y_cols + (a.loss.y_cols == 1 ? 0 : lane)];
+        float dy;
+        lsum += loss_elem(a.loss, a.Q, lane, loss_tau(a.loss, lane), mine, yup, ydn, yt, a.grad_scale, dy);
+        if (a.dY) a.dY[(size_t)grow * a.Q + lane] = dy;
+      }
+    }
   }
   STAMP(14);
   if (a.y && a.loss_sum) {
+    lsum = wave_sum(lsum);
     if (lane == 0) red[wave] = lsum;
     lds_barrier();
     if (tid == 0) {

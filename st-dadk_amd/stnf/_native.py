@@ -38,6 +38,15 @@ class BasisDesc(C.Structure):
                 ("t_bw", C.c_void_p)]
 
 
+MAX_Q = 8
+LOSS_MSE, LOSS_PINBALL = 0, 1
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("y_cols", C.c_int32), ("tau", C.c_float * MAX_Q),
+                ("nc_weight", C.c_float), ("nc_power", C.c_int32)]
+
+
 FLAG_DENSE = 1
 FLAG_W0_T = 2
 
@@ -60,6 +69,13 @@ _SIGNATURES = {
                                           C.POINTER(C.c_void_p), C.c_void_p]),
     "stdadk_mse_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
+    "stdadk_loss_f32": (C.c_int, [C.POINTER(LossDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stdadk_delta_head_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "stdadk_delta_head_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                 C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "stdadk_step_uses_window": (C.c_int32, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.c_int32]),
     "stdadk_step_workspace_bytes": (C.c_size_t, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.c_int64,
                                                  C.c_int32]),
@@ -73,6 +89,7 @@ _SIGNATURES = {
     "stdadk_train_fwd_bwd_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc),
                                            C.POINTER(MlpTensors), C.POINTER(MlpTensors), C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                           C.POINTER(LossDesc),
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "stdadk_gather_batch_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -111,7 +128,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError => the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.stdadk_abi_version() != 2:
+        if handle.stdadk_abi_version() != 3:
             raise NativeLibraryError("libstdadk.so ABI version mismatch")
         _lib = handle
     return _lib
@@ -287,11 +304,75 @@ def backward(basis, desc, params, grads, B, dY, workspace, flags, seed=0, step_d
     _check(rc, "stdadk_backward_f32")
 
 
+def make_loss(kind="mse", Q=1, y_cols=None, taus=None, nc_weight=0.0, nc_power=1):
+    """stdadk_loss_desc for an objective on (B,Q) predictions: kind "mse" or "pinball" (check loss
+    with levels `taus`, optional prediction-level non-crossing penalty)."""
+    if kind not in ("mse", "pinball"):
+        raise ValueError(f"unknown loss kind '{kind}'; use 'mse' or 'pinball'")
+    if Q < 1 or Q > MAX_Q:
+        raise ValueError(f"Q={Q} outside 1..{MAX_Q}")
+    ld = LossDesc()
+    ld.kind = LOSS_MSE if kind == "mse" else LOSS_PINBALL
+    ld.y_cols = Q if y_cols is None else int(y_cols)
+    if kind == "pinball":
+        taus = list(taus if taus is not None else [])
+        if len(taus) != Q:
+            raise ValueError(f"pinball loss needs {Q} quantile levels, got {len(taus)}")
+        for i, q in enumerate(taus):
+            ld.tau[i] = float(q)
+        if nc_weight and int(nc_power) not in (1, 2):
+            raise ValueError(f"Unsupported power={nc_power}; use 1 or 2.")
+        ld.nc_weight = float(nc_weight)
+        ld.nc_power = int(nc_power)
+    return ld
+
+
+def loss(desc, y_pred, y, grad_scale, dY=None, loss_sum=None):
+    """stdadk_loss_f32 on y_pred (B,Q), y (B,y_cols); desc None = MSE."""
+    B, Q = y_pred.shape
+    rc = lib().stdadk_loss_f32(C.byref(desc) if desc is not None else None, _dev(y_pred, "y_pred"),
+                               _dev(y, "y"), B, Q, grad_scale, _dev(dY, "dY"), _dev(loss_sum, "loss_sum"),
+                               _stream())
+    _check(rc, "stdadk_loss_f32")
+
+
+def _rows(tensor, name, cols):
+    """Address + row stride of a (Q, cols) fp32 device matrix whose rows are contiguous."""
+    if not tensor.is_cuda or tensor.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected a float32 tensor on a HIP device, got {tensor.dtype} on "
+                           f"{tensor.device}; the MI355X build of stnf has no CPU path")
+    if tensor.dim() != 2 or tensor.shape[1] != cols or (cols > 1 and tensor.stride(1) != 1):
+        raise RuntimeError(f"{name}: expected shape (Q, {cols}) with contiguous rows, got {tuple(tensor.shape)}")
+    return tensor.data_ptr(), tensor.stride(0)
+
+
+def delta_head(delta, Wo, bo):
+    """delta (Q, d+1) rows (any row stride) -> Wo (Q,d), bo (Q): cumulative sums over quantiles."""
+    Q, d = Wo.shape
+    ptr, ldd = _rows(delta, "delta", d + 1)
+    rc = lib().stdadk_delta_head_f32(ptr, ldd, Q, d, _dev(Wo, "Wo"), _dev(bo, "bo"), _stream())
+    _check(rc, "stdadk_delta_head_f32")
+
+
+def delta_head_backward(delta, dWo, dbo, lambda_grad, lambda_loss, d_delta, loss_sum=None):
+    Q, d = dWo.shape
+    ptr, ldd = _rows(delta, "delta", d + 1)
+    gptr, ldg = _rows(d_delta, "d_delta", d + 1)
+    if ldg != ldd:
+        raise RuntimeError("delta_head_backward: delta and d_delta must share the row stride")
+    rc = lib().stdadk_delta_head_backward_f32(ptr, _dev(dWo, "dWo"), _dev(dbo, "dbo"), ldd, Q, d,
+                                              lambda_grad, lambda_loss, gptr, _dev(loss_sum, "loss_sum"),
+                                              _stream())
+    _check(rc, "stdadk_delta_head_backward_f32")
+
+
 def train_fwd_bwd(basis, desc, params, grads, coords, t, X, y, B, grad_scale, loss_sum, y_pred,
-                  workspace, flags, seed=0, step_dev=None, aux_stream=None):
+                  workspace, flags, seed=0, step_dev=None, aux_stream=None, loss_desc=None):
     rc = lib().stdadk_train_fwd_bwd_f32(C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads),
                                         _dev(coords, "coords"), _dev(t, "t"), _dev(X, "X"), _dev(y, "y"),
-                                        B, grad_scale, _dev(loss_sum, "loss_sum"), _dev(y_pred, "y_pred"),
+                                        B, grad_scale,
+                                        C.byref(loss_desc) if loss_desc is not None else None,
+                                        _dev(loss_sum, "loss_sum"), _dev(y_pred, "y_pred"),
                                         workspace.data_ptr(),
                                         workspace.numel() * workspace.element_size(), seed,
                                         _dev(step_dev, "step_dev"), flags, _stream(),

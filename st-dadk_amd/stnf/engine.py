@@ -35,7 +35,7 @@ def flatten_parameters(model, transpose_first=True):
         offs.append((n, total, p.numel()))
         total += (p.numel() + 3) // 4 * 4
     flat = torch.zeros(total, device=dev, dtype=torch.float32)
-    first_w = model.mlp[0].weight
+    first_w = model._body[0].weight
     for (n, p), (_, o, k) in zip(params, offs):
         if transpose_first and p is first_w:
             out_f, in_f = p.shape
@@ -48,12 +48,31 @@ def flatten_parameters(model, transpose_first=True):
 
 
 class TrainStep:
-    """One fused optimisation step of STInterpMLP (fixed knots, MSE)."""
+    """One fused optimisation step of STInterpMLP (fixed knots).
+
+    Objective (scripts/train_st_interp.py:617-658): loss="mse" (regression_type 'mean'), or
+    loss="pinball" with `quantile_levels` — one level = 'quantile', several = 'multi-quantile' (mean
+    over levels of the per-level check loss on (B,1) targets) plus either the prediction-level
+    non-crossing penalty (non_crossing_weight, non_crossing_power) or, with the delta head, the
+    parameter-level P_nc(delta) (non_crossing_lambda)."""
 
     def __init__(self, model, lr=2e-2, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
                  grad_clip=10.0, ema_decay=None, max_batch=4096, use_graph=False,
-                 process_group=None, distributed=None, force_dense=False, two_streams=False):
+                 process_group=None, distributed=None, force_dense=False, two_streams=False,
+                 loss="mse", quantile_levels=None, non_crossing_weight=0.0, non_crossing_power=1,
+                 non_crossing_lambda=0.0):
         self.model = model
+        if loss not in ("mse", "pinball"):
+            raise ValueError(f"unknown loss '{loss}'; use 'mse' or 'pinball'")
+        self.loss_kind = loss
+        self.quantile_levels = [float(q) for q in quantile_levels] if quantile_levels is not None else None
+        if loss == "pinball" and (self.quantile_levels is None
+                                  or len(self.quantile_levels) != model.output_dim):
+            raise ValueError(f"pinball loss needs output_dim={model.output_dim} quantile levels")
+        self.nc_weight = 0.0 if model._has_delta else float(non_crossing_weight)
+        self.nc_power = int(non_crossing_power)
+        self.nc_lambda = float(non_crossing_lambda) if model._has_delta else 0.0
+        self._loss_descs = {}
         self.dev = next(model.parameters()).device
         if self.dev.type != "cuda":
             raise RuntimeError("TrainStep needs the model on a HIP device; there is no CPU path")
@@ -71,18 +90,27 @@ class TrainStep:
         assert self.state.w0_transposed
         self.uses_window = N.step_uses_window(self.state.basis, self.state.desc, self.state.flags)
         # gradient views in _param_list() order; dW0 is stored transposed like W0
-        views = []
+        views, dviews = [], []
         by_name = {n: (o, k) for n, o, k in self.offsets}
-        first_w = model.mlp[0].weight
+        first_w = model._body[0].weight
         for n, p in model.named_parameters():
             if p.requires_grad:
                 o, k = by_name[n]
                 if p is first_w:
                     views.append(self.grad[o:o + k].view(p.shape[1], p.shape[0]))
+                elif n.startswith("delta_params."):
+                    dviews.append(self.grad[o:o + k])
                 else:
                     views.append(self.grad[o:o + k].view(p.shape))
         self.grad_views = views
-        self.grads_t = model._pack(views)
+        self.d_head = self.d_delta = None
+        if model._has_delta:
+            # the library differentiates w.r.t. the derived output layer; dWo/dbo are scratch and
+            # stdadk_delta_head_backward_f32 folds them into the delta rows of the flat gradient
+            self.d_head = [torch.empty_like(self.state.head[0]), torch.empty_like(self.state.head[1])]
+            self.d_delta = model._delta_matrix(dviews)
+            assert self.d_delta.data_ptr() == dviews[0].data_ptr() and self.state.delta.stride(0) == self.d_delta.stride(0)
+        self.grads_t = model._pack(views + (self.d_head or []))
         B = self.max_batch
         self.ws = torch.empty(N.step_workspace_bytes(self.state.basis, self.state.desc, B, self.state.flags) // 4,
                               device=self.dev)
@@ -121,10 +149,19 @@ class TrainStep:
         """All kernels of one step on the current stream (capturable: no sync, no allocation)."""
         st = self.state
         Q = self.model.output_dim
+        if st.head is not None:
+            N.delta_head(st.delta, st.head[0], st.head[1])          # output layer of this step's delta
         # d(mean over the GLOBAL batch)/dparams: each rank scales by 1/global_rows, the all-reduce SUMs
         N.train_fwd_bwd(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, B,
                         D.grad_scale(global_rows, Q), self.loss_sum, None, self.ws, st.flags,
-                        seed=self.seed, step_dev=self.step_dev, aux_stream=self.aux_stream)
+                        seed=self.seed, step_dev=self.step_dev, aux_stream=self.aux_stream,
+                        loss_desc=self._loss_desc(y.shape[1]))
+        if st.head is not None:
+            # every rank adds 1/world of the parameter-level penalty gradient (the all-reduce SUMs);
+            # the loss accumulator is in units of rows*Q like the data term
+            N.delta_head_backward(st.delta, self.d_head[0], self.d_head[1], self.nc_lambda / self.world,
+                                  self.nc_lambda * B * Q, self.d_delta,
+                                  self.loss_sum if self.nc_lambda != 0.0 else None)
         if self.distributed:
             D.allreduce_gradients(self.grad, self.pg)
         if self.grad_clip > 0:
@@ -134,6 +171,18 @@ class TrainStep:
         N.adamw_ema(self.flat, self.grad, self.m, self.v, self.ema, self.lr, self.betas, self.eps,
                     self.wd, self.step_count + 1, max_norm=self.grad_clip, sumsq_parts=self.sumsq,
                     ema_decay=self.ema_decay, lr_dev=self.lr_dev, step_dev=self.step_dev)
+
+    def _loss_desc(self, y_cols):
+        """ABI loss descriptor for targets with `y_cols` columns (None = the plain MSE fast path)."""
+        Q = self.model.output_dim
+        if y_cols not in (1, Q):
+            raise RuntimeError(f"targets have {y_cols} columns; expected 1 or output_dim={Q}")
+        if self.loss_kind == "mse" and y_cols == Q:
+            return None
+        if y_cols not in self._loss_descs:
+            self._loss_descs[y_cols] = N.make_loss(self.loss_kind, Q, y_cols, self.quantile_levels,
+                                                   self.nc_weight, self.nc_power)
+        return self._loss_descs[y_cols]
 
     def step(self, X, coords, t, y, global_rows=None):
         """One optimisation step on device tensors coords (B,2), t (B,1)/(B,), y (B,Q), X (B,p)|None.
@@ -168,11 +217,11 @@ class TrainStep:
             raise RuntimeError(f"batch {B} > max_batch {self.max_batch}")
         if global_rows is None:
             global_rows = B * self.world
-        p, Q = self.model.p, self.model.output_dim
-        if self._ix is None or self._ix[0].numel() != B:
+        p, yc = self.model.p, y_all.shape[1]
+        if self._ix is None or self._ix[0].numel() != B or self._ix[3].shape[1] != yc:
             self._ix = (torch.empty(B, dtype=torch.int64, device=self.dev),
                         torch.empty(B, 2, device=self.dev), torch.empty(B, device=self.dev),
-                        torch.empty(B, Q, device=self.dev),
+                        torch.empty(B, yc, device=self.dev),
                         torch.empty(B, p, device=self.dev) if p > 0 else None)
             self._ix_graph = None
         ib, cb, tb, yb, xb = self._ix
@@ -209,12 +258,12 @@ class TrainStep:
             self._warm = True
             self._enqueue(X, coords, t, y, B, global_rows)
             return
-        if self._graph is None or self._g_B != (B, global_rows):
+        if self._graph is None or self._g_B != (B, global_rows, y.shape[1]):
             p = self.model.p
             self._g_in = (torch.empty(B, p, device=self.dev) if p > 0 else None,
                           torch.empty(B, 2, device=self.dev), torch.empty(B, device=self.dev),
-                          torch.empty(B, self.model.output_dim, device=self.dev))
-            self._g_B = (B, global_rows)
+                          torch.empty(B, y.shape[1], device=self.dev))
+            self._g_B = (B, global_rows, y.shape[1])
             # AdamW and the dropout generator read lr / step from device scalars, so a replay
             # advances them; capture itself executes nothing
             torch.cuda.synchronize()
@@ -229,7 +278,8 @@ class TrainStep:
         self._graph.replay()
 
     def mean_loss(self, reset=True):
-        """Mean squared error over the rows seen since the last reset (ONE host sync)."""
+        """Mean batch objective (MSE, or check loss + penalties) over the rows seen since the last
+        reset (ONE host sync)."""
         val = self.loss_sum.item() / max(self.rows_seen * self.model.output_dim, 1)
         if reset:
             self.loss_sum.zero_()

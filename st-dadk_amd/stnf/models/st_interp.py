@@ -18,8 +18,8 @@ import torch.nn as nn
 
 from .. import _native as N
 
-_SCOPE_MSG = ("is outside the MI355X hot path built so far (fixed uniform knots, mean regression; "
-              "SURVEY.md §8 'next' rows N2/N3)")
+_SCOPE_MSG = ("is outside the MI355X hot path built so far (fixed uniform knots; "
+              "SURVEY.md §8 'next' row N2)")
 
 
 def _round_up(a, b):
@@ -142,23 +142,31 @@ class _StepFunction(torch.autograd.Function):
     def backward(ctx, dY):
         (ws,) = ctx.saved_tensors
         model, st = ctx.model, ctx.st
-        plist = model._param_list()
+        plist = model._body_params()
         grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in plist]
+        head = []
+        if st.head is not None:
+            head = [torch.empty_like(st.head[0]), torch.empty_like(st.head[1])]      # dWo, dbo
         if st.w0_transposed:
             # dW0 arrives as dW0^T (in,out); hand autograd its transpose view, shape (out,in)
             g0t = torch.empty(plist[0].shape[1], plist[0].shape[0], device=dY.device, dtype=torch.float32)
             grads[0] = g0t.t()
-            gt = model._pack([g0t] + grads[1:])
+            gt = model._pack([g0t] + grads[1:] + head)
         else:
-            gt = model._pack(grads)
+            gt = model._pack(grads + head)
         N.backward(st.basis, st.desc, st.params, gt, ctx.B, dY.contiguous().float(), ws, st.flags,
                    seed=ctx.seed)
+        if st.head is not None:
+            # d delta_l = sum_{k>=l} d beta_k; the parameter-level penalty stays with the caller's autograd
+            dd = torch.empty(model.output_dim, model.last_hidden_dim + 1, device=dY.device)
+            N.delta_head_backward(st.delta, head[0], head[1], 0.0, 0.0, dd)
+            grads += list(dd.unbind(0))
         return (None, None, None, None, None) + tuple(grads)
 
 
 class _StepState:
     """ABI descriptors for one forward/backward pair (keeps the tensors they point to alive)."""
-    __slots__ = ("basis", "desc", "params", "flags", "w0_transposed", "keep")
+    __slots__ = ("basis", "desc", "params", "flags", "w0_transposed", "keep", "delta", "head")
 
 
 class STInterpMLP(nn.Module):
@@ -203,42 +211,87 @@ class STInterpMLP(nn.Module):
             prev = h
         self.last_hidden_dim = prev
         if use_delta_reparameterization and output_dim > 1:
-            raise NotImplementedError(f"use_delta_reparameterization=True {_SCOPE_MSG}")
-        layers.append(nn.Linear(prev, self.output_dim))
-        self.mlp = nn.Sequential(*layers)
-        self.mlp_trunk = None
-        self.delta_params = None
+            if output_dim > N.MAX_Q:
+                raise NotImplementedError(f"delta head with more than {N.MAX_Q} quantiles {_SCOPE_MSG}")
+            # shared trunk + one delta_k = (delta_k0 | delta_k1..d) per quantile; the output rows are
+            # their cumulative sums (reference :671-686, 849-877)
+            self.mlp_trunk = nn.Sequential(*layers)
+            self.delta_params = nn.ParameterList([nn.Parameter(torch.zeros(prev + 1))
+                                                  for _ in range(output_dim)])
+            for delta_k in self.delta_params:
+                nn.init.normal_(delta_k, mean=0.0, std=0.01)
+        else:
+            layers.append(nn.Linear(prev, self.output_dim))
+            self.mlp = nn.Sequential(*layers)
+            self.mlp_trunk = None
+            self.delta_params = None
         # diagnostics: True forces the materialising (dense) kernels even where the window path applies
         self.force_dense_path = False
 
     # ---- native plumbing ---------------------------------------------------------------
+    @property
+    def _has_delta(self):
+        return self.delta_params is not None
+
+    @property
+    def _body(self):
+        """The nn.Sequential holding the Linear/LayerNorm stack: `mlp`, or `mlp_trunk` under the delta head."""
+        return self.mlp_trunk if self._has_delta else self.mlp
+
     def _linears(self):
-        return [m for m in self.mlp if isinstance(m, nn.Linear)]
+        return [m for m in self._body if isinstance(m, nn.Linear)]
 
     def _lns(self):
-        return [m for m in self.mlp if isinstance(m, nn.LayerNorm)]
+        return [m for m in self._body if isinstance(m, nn.LayerNorm)]
+
+    def _body_params(self):
+        return [p for m in self._body for p in m.parameters(recurse=False)]
 
     def _param_list(self):
-        """Parameters in nn.Sequential order == order of named_parameters()."""
-        return [p for m in self.mlp for p in m.parameters(recurse=False)]
+        """Parameters in registration order == order of named_parameters()."""
+        return self._body_params() + (list(self.delta_params) if self._has_delta else [])
 
     def _pack(self, flat_list):
-        """flat list in _param_list() order -> ABI struct."""
+        """Tensors in _body_params() order (+ the derived [Wo, bo] under the delta head) -> ABI struct."""
         it = iter(flat_list)
         Ws, bs, gs, betas = [], [], [], []
-        for m in self.mlp:
+        for m in self._body:
             if isinstance(m, nn.Linear):
                 Ws.append(next(it)); bs.append(next(it))
             elif isinstance(m, nn.LayerNorm):
                 gs.append(next(it)); betas.append(next(it))
+        if self._has_delta:
+            Ws.append(next(it)); bs.append(next(it))
         return N.make_tensors(Ws, bs, gs if self.layernorm else None, betas if self.layernorm else None)
+
+    def _delta_matrix(self, tensors=None):
+        """(Q, d+1) matrix of the delta vectors (or of `tensors`, e.g. their gradients): a strided
+        view when they sit equally spaced in one buffer (TrainStep's flat storage), else a stacked copy."""
+        ps = [p.data for p in self.delta_params] if tensors is None else list(tensors)
+        Q, d1 = len(ps), ps[0].numel()
+        base = ps[0]
+        stride = (ps[1].data_ptr() - base.data_ptr()) // 4 if Q > 1 else d1
+        same = stride >= d1 and all(
+            q.is_contiguous() and q.untyped_storage().data_ptr() == base.untyped_storage().data_ptr()
+            and q.data_ptr() - base.data_ptr() == 4 * stride * k for k, q in enumerate(ps))
+        if same:
+            return torch.as_strided(base, (Q, d1), (stride, 1))
+        return torch.stack(ps)
+
+    def _delta_head(self, delta=None):
+        """Output layer (Wo (Q,d), bo (Q,)) of the delta head: stdadk_delta_head_f32."""
+        delta = self._delta_matrix() if delta is None else delta
+        Wo = torch.empty(self.output_dim, self.last_hidden_dim, device=delta.device)
+        bo = torch.empty(self.output_dim, device=delta.device)
+        N.delta_head(delta, Wo, bo)
+        return Wo, bo
 
     def _native_desc(self, training=True):
         return N.make_desc(self.input_dim, self.hidden_dims, self.output_dim, self.layernorm,
                            self.dropout_p if training else 0.0)
 
     def _native_tensors(self):
-        return self._pack([p.data for p in self._param_list()])
+        return self._pack([p.data for p in self._body_params()] + (list(self._delta_head()) if self._has_delta else []))
 
     def _basis_desc(self):
         sb, tb = self.spatial_basis, self.temporal_basis
@@ -253,7 +306,12 @@ class STInterpMLP(nn.Module):
         st = _StepState()
         st.desc = self._native_desc(training)
         st.basis = self._basis_desc()
-        tensors = [p.data for p in self._param_list()]
+        tensors = [p.data for p in self._body_params()]
+        st.delta = st.head = None
+        if self._has_delta:
+            st.delta = self._delta_matrix()
+            st.head = self._delta_head(st.delta)        # refreshed by the owner whenever delta changes
+            tensors += list(st.head)
         w0 = tensors[0]
         st.keep = None
         flags = N.FLAG_DENSE if force_dense else 0
@@ -292,7 +350,10 @@ class STInterpMLP(nn.Module):
         return self.spatial_basis.compute_movement_penalty()
 
     def get_delta_parameters(self):
-        return None     # delta head not enabled (reference :720-721)
+        """List of the delta_k parameters, or None without the delta head (reference :712-722)."""
+        if not self.use_delta_reparameterization or self.delta_params is None:
+            return None
+        return list(self.delta_params)
 
     def compute_sparsity_penalty(self, penalty_type='element', lambda_l1=0.01, lambda_group=0.01):
         """L1 / group-lasso penalties on the first layer's basis columns (reference :724-825);
@@ -303,7 +364,7 @@ class STInterpMLP(nn.Module):
         if penalty_type == 'none':
             z = torch.tensor(0.0, device=dev)
             return {'spatial_penalty': z, 'temporal_penalty': z.clone(), 'total_penalty': z.clone()}
-        w = self.mlp[0].weight
+        w = self._body[0].weight
         blocks = (w[:, self.p:self.p + self.k_spatial],
                   w[:, self.p + self.k_spatial:self.p + self.k_spatial + self.k_temporal])
         pens = []

@@ -678,3 +678,258 @@ def test_reference_style_loop_matches_engine():
         v2 = m2(None, coords, t)
     eng.swap_in_ema()
     assert torch.allclose(v1, v2, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ N3: quantile objectives + delta head
+def build_quantile_model(name, dropout=0.0):
+    from stnf.models import STInterpMLP
+    cfg, lc = cases.quantile_cfg(name)
+    m = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"],
+                    k_temporal_centers=cfg["k_temporal_centers"], hidden_dims=cfg["hidden_dims"],
+                    dropout=dropout, layernorm=cfg["layernorm"], spatial_basis_function=cfg["basis"],
+                    output_dim=cfg["output_dim"], use_delta_reparameterization=cfg["delta"])
+    st = cases.make_state(cfg)
+    assert [k for k, _ in m.named_parameters()] == list(st.keys())      # reference state_dict keys
+    with torch.no_grad():
+        for (_, p), (k, v) in zip(m.named_parameters(), st.items()):
+            assert tuple(p.shape) == v.shape, k
+            p.copy_(torch.from_numpy(v.copy()))
+    return m.to(dev()), cfg, lc
+
+
+@pytest.mark.parametrize("Q,ycols,nc_w,nc_p", [(1, 1, 0.0, 1), (5, 1, 0.0, 1), (5, 1, 0.7, 1), (5, 1, 1.3, 2),
+                                                 (8, 8, 0.4, 2), (3, 1, 2.0, 1)])
+def test_loss_kernel_matches_oracle(Q, ycols, nc_w, nc_p):
+    """stdadk_loss_f32 (check loss + non-crossing, broadcast targets, sub-gradients at the kinks)."""
+    from stnf import _native as N
+    rs = np.random.RandomState(100 + Q)
+    B = 1031
+    yp = rs.standard_normal((B, Q)).astype(np.float32)
+    y = rs.standard_normal((B, ycols)).astype(np.float32)
+    yp[:7, 0] = y[:7, 0]                       # e == 0: max() tie, gradient 1/2 - tau
+    if Q > 1:
+        yp[7:14, 1] = yp[7:14, 0]              # q_k == q_{k+1}: relu'(0) = 0
+    taus = list(np.linspace(0.05, 0.95, Q)) if Q > 1 else [0.9]
+    desc = N.make_loss("pinball", Q, ycols, taus, nc_w, nc_p)
+    d = dev()
+    dY = torch.empty(B, Q, device=d)
+    acc = torch.zeros(1, device=d)
+    gs = 1.0 / (B * Q)
+    N.loss(desc, torch.from_numpy(yp).to(d), torch.from_numpy(y).to(d), gs, dY, acc)
+    if ycols == 1:
+        L, g = orc.quantile_objective(yp, y, taus, nc_w, nc_p)
+    else:   # column-wise targets: evaluate the check loss per column, penalty on the predictions
+        L0, g = orc.quantile_objective(yp, np.zeros((B, 1)), taus, nc_w, nc_p)
+        Lz, gz = orc.quantile_objective(yp, np.zeros((B, 1)), taus, 0.0, 1)
+        Lc = np.mean([orc.check_loss(yp[:, q], y[:, q], taus[q]) for q in range(Q)])
+        gc = np.stack([orc.quantile_objective(yp[:, q:q + 1], y[:, q:q + 1], [taus[q]])[1][:, 0] / Q
+                       for q in range(Q)], axis=1)
+        L, g = L0 - Lz + Lc, g - gz + gc
+    assert abs(acc.item() * gs - L) <= 1e-5 * max(1.0, abs(L))
+    # the kinks are hit exactly, so the gradient is comparable element by element
+    assert np.abs(dY.cpu().numpy() - g).max() <= 1e-6 * np.abs(g).max()
+    # MSE through the same entry point, broadcast targets
+    if ycols == 1:
+        acc.zero_()
+        N.loss(N.make_loss("mse", Q, 1), torch.from_numpy(yp).to(d), torch.from_numpy(y).to(d), gs, dY, acc)
+        ref = ((yp.astype(np.float64) - y) ** 2)
+        assert abs(acc.item() - ref.sum()) <= 1e-5 * ref.sum()
+        assert np.abs(dY.cpu().numpy() - 2 * (yp.astype(np.float64) - y) * gs).max() <= 1e-6 * gs * 10
+
+
+def test_delta_head_kernels_match_oracle_and_reference():
+    from stnf import _native as N
+    g = load("n3_known_answers")
+    delta64 = g["ka_delta"]                           # incl. J = 0, tie and clamp-boundary rows
+    d = dev()
+    Q, d1 = delta64.shape
+    # rows embedded in a wider buffer, as TrainStep's flat storage has them (stride 12 > d+1 = 9)
+    buf = torch.zeros(Q, 12, device=d)
+    buf[:, :d1] = torch.from_numpy(delta64).float()
+    delta = buf[:, :d1]
+    Wo, bo = torch.empty(Q, d1 - 1, device=d), torch.empty(Q, device=d)
+    N.delta_head(delta, Wo, bo)
+    Wr, br = orc.delta_head(delta64.astype(np.float32))
+    assert np.abs(Wo.cpu().numpy() - Wr).max() < 1e-6 and np.abs(bo.cpu().numpy() - br).max() < 1e-6
+    rs = np.random.RandomState(3)
+    dW, db = rs.standard_normal((Q, d1 - 1)).astype(np.float32), rs.standard_normal(Q).astype(np.float32)
+    gbuf = torch.zeros(Q, 12, device=d)
+    acc = torch.zeros(1, device=d)
+    N.delta_head_backward(delta, torch.from_numpy(dW).to(d), torch.from_numpy(db).to(d), 0.3, 2.0,
+                          gbuf[:, :d1], acc)
+    P, gP = orc.p_nc_delta(delta64.astype(np.float32))
+    ref = orc.delta_head_backward(dW, db) + 0.3 * gP
+    assert np.abs(gbuf[:, :d1].cpu().numpy() - ref).max() < 1e-5
+    assert (gbuf[:, d1:] == 0).all()
+    assert abs(acc.item() - 2.0 * P) < 1e-5
+    # the reference's own value and gradient of P_nc(delta) on the same vector
+    assert abs(P - float(g["ka_pnc"])) < 1e-6
+    assert np.abs(gP - g["ka_pnc_grad"]).max() < 1e-12
+    from stnf import losses
+    ps = [torch.from_numpy(delta64[k]).float().to(d) for k in range(Q)]
+    assert abs(losses.compute_p_nc_delta_penalty(ps).item() - float(g["ka_pnc"])) < 1e-5
+    assert losses.compute_p_nc_delta_penalty(ps[:1]).item() == 0.0
+    assert losses.compute_p_nc_delta_penalty(None).item() == 0.0
+
+
+def test_losses_module_known_answers():
+    """stnf.losses on the device against values of the reference's functions (incl. the vectors of
+    its tests test_crps_eq_4_6.py)."""
+    from stnf import losses
+    g = load("n3_known_answers")
+    d = dev()
+    yp, y = torch.from_numpy(g["ka_yp"]).float().to(d), torch.from_numpy(g["ka_y"]).float().to(d)
+    for i, q in enumerate(cases.TAUS5):
+        assert abs(losses.quantile_loss(yp[:, i:i + 1], y, q).item() - float(g[f"ka_qloss_{i}"])) < 1e-6
+    assert abs(losses.non_crossing_penalty(yp, "mean", 1).item() - float(g["ka_nc1"])) < 1e-5
+    assert abs(losses.non_crossing_penalty(yp, "sum", 2).item() - float(g["ka_nc2_sum"])) < 1e-3
+    assert losses.non_crossing_penalty(yp[:, :1]).item() == 0.0
+    with pytest.raises(ValueError, match="Unsupported power"):
+        losses.non_crossing_penalty(yp, "mean", 3)
+    with pytest.raises(ValueError, match="Unsupported reduction"):
+        losses.non_crossing_penalty(yp, "median", 1)
+    assert abs(losses.compute_crps_multi_quantile(yp, y, cases.TAUS5) - float(g["ka_crps"])) < 1e-6
+    assert abs(losses.compute_crps_multi_quantile(g["ka_yp"], g["ka_y"], cases.TAUS5,
+                                                  weights=np.array([1.0, 2.0, 3.0, 2.0, 1.0]))
+               - float(g["ka_crps_w"])) < 1e-12
+    yt = np.array([2.0, 3.0, 4.0, 5.0])
+    pd = {0.05: yt - 1.0, 0.25: yt - 0.5, 0.5: yt.copy(), 0.75: yt + 0.5, 0.95: yt + 1.0}
+    assert abs(losses.compute_crps(pd, yt) - float(g["ka_crps_thesis"])) < 1e-15
+    assert abs(losses.compute_crps({0.5: np.array([2.5])}, np.array([2.0])) - float(g["ka_crps_single"])) < 1e-15
+    with pytest.raises(ValueError, match="cannot be empty"):
+        losses.compute_crps({}, yt)
+    with pytest.raises(ValueError, match="weights length"):
+        losses.compute_crps({0.5: yt, 0.9: yt}, yt, weights=np.array([0.5]))
+
+
+def _torch_n3_loss(m, yp, y, lc):
+    """The batch objective as the reference's driver composes it from torch ops
+    (train_st_interp.py:622-658), on this package's differentiable forward()."""
+    def ql(a, q):
+        e = y - a
+        return torch.mean(torch.max((q - 1) * e, q * e))
+    taus = lc["taus"]
+    if len(taus) == 1:
+        return ql(yp, taus[0])
+    loss = torch.mean(torch.stack([ql(yp[:, i:i + 1], q) for i, q in enumerate(taus)]))
+    if lc.get("delta"):
+        pen = torch.zeros((), device=yp.device)
+        for dk in m.get_delta_parameters()[1:]:
+            S = torch.clamp(-dk[1:], min=0.0).sum()
+            pen = pen + dk[0] - torch.max(dk[0], S)
+        return loss + lc.get("nc_lambda", 0.0) * pen
+    if lc.get("nc_weight", 0.0) > 0:
+        v = torch.relu(yp[:, :-1] - yp[:, 1:])
+        if lc.get("nc_power", 1) == 2:
+            v = v ** 2
+        loss = loss + lc["nc_weight"] * v.sum(1).mean()
+    return loss
+
+
+@pytest.mark.parametrize("name", list(cases.QUANTILE_CASES))
+def test_quantile_module_loop_matches_reference(name):
+    """forward() + the driver's torch loss + backward() (autograd through the C ABI, delta head
+    included) against the float64 golden of the reference."""
+    m, cfg, lc = build_quantile_model(name)
+    g = load(name)
+    d = dev()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    m.train()
+    yp = m(X, coords, t)
+    assert yp.shape == (cfg["B"], cfg["output_dim"])
+    assert np.abs(yp.detach().cpu().numpy() - g["y64"]).max() <= TOL * max(1.0, np.abs(g["y64"]).max())
+    loss = _torch_n3_loss(m, yp, y, lc)
+    assert abs(loss.item() - float(g["loss64"])) <= 2 * TOL * max(1.0, abs(float(g["loss64"])))
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(p.shape), k
+        check_vs_digest(p.grad.cpu().numpy(), g, "g", k, cfg["seed"] + 7, tol=2e-5)
+    if cfg["delta"]:
+        # beta_k = sum_{l<=k} delta_l through the torch trunk, as the reference's test does
+        with torch.no_grad():
+            m.eval()
+            feats = m.build_features(X, coords, t)[:, :m.input_dim]
+            h = m.mlp_trunk(feats)
+            beta = torch.cumsum(torch.stack(list(m.delta_params)), dim=0)
+            ref = beta[:, :1].t() + h @ beta[:, 1:].t()
+            got = m(X, coords, t)
+        assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("name", list(cases.QUANTILE_CASES))
+def test_quantile_engine_steps_match_reference(name, dense):
+    """OPT['steps'] fused steps with the check loss / non-crossing / delta head inside the step."""
+    from stnf.engine import TrainStep
+    m, cfg, lc = build_quantile_model(name)
+    g = load(name)
+    o = cases.OPT
+    d = dev()
+    m.train()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    eng = TrainStep(m, lr=o["lr"], weight_decay=o["weight_decay"], betas=o["betas"], eps=o["eps"],
+                    grad_clip=o["grad_clip"], ema_decay=o["ema_decay"], max_batch=cfg["B"], force_dense=dense,
+                    loss="pinball", quantile_levels=lc["taus"], non_crossing_weight=lc.get("nc_weight", 0.0),
+                    non_crossing_power=lc.get("nc_power", 1), non_crossing_lambda=lc.get("nc_lambda", 0.0))
+    losses = []
+    for _ in range(o["steps"]):
+        eng.step(X if cfg["p"] else None, coords, t, y)
+        losses.append(eng.mean_loss())
+    ref = g["opt_losses64"]
+    assert np.abs(np.array(losses) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (losses, ref)
+    for k, p in m.named_parameters():
+        check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=1e-4)
+    eng.swap_in_ema()
+    for k, p in m.named_parameters():
+        check_vs_digest(p.detach().cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=1e-4)
+    eng.swap_in_ema()
+
+
+def test_quantile_engine_graph_and_indexed():
+    """Graph replay of the quantile step (delta head + P_nc inside the capture) == eager, and
+    step_indexed gathers (N,1) targets for a (B,5) head."""
+    from stnf.engine import TrainStep
+    d = dev()
+    res = []
+    for graph in (False, True):
+        m, cfg, lc = build_quantile_model("default227_delta5")
+        m.train()
+        X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+        eng = TrainStep(m, lr=1e-3, grad_clip=10.0, ema_decay=0.99, max_batch=64, use_graph=graph,
+                        loss="pinball", quantile_levels=lc["taus"], non_crossing_lambda=0.05)
+        for s in range(4):
+            idx = torch.arange(64, device=d) + 16 * s
+            eng.step_indexed(coords, t, y, idx)
+        res.append((torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone(), eng.mean_loss()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert abs(res[0][1] - res[1][1]) <= 1e-6 * max(1.0, abs(res[0][1]))
+
+
+def test_delta_model_surface():
+    """The reference's delta-head API (tests/stnf/models/test_st_interp_delta_reparameterization.py)."""
+    from stnf.models import STInterpMLP, create_model
+    d = dev()
+    m = STInterpMLP(p=0, k_spatial_centers=[9], k_temporal_centers=[5], hidden_dims=[32, 16], output_dim=5,
+                    use_delta_reparameterization=True).to(d)
+    assert m.mlp_trunk is not None and len(m.delta_params) == 5 and m.last_hidden_dim == 16
+    assert all(tuple(p.shape) == (17,) for p in m.get_delta_parameters())
+    assert all(p.abs().max().item() < 0.1 for p in m.delta_params)          # N(0, 0.01) init
+    coords, t = torch.rand(10, 2, device=d), torch.rand(10, 1, device=d)
+    m.eval()
+    with torch.no_grad():
+        y1, y2 = m(torch.empty(10, 0, device=d), coords, t), m(None, coords, t)
+    assert y1.shape == (10, 5) and torch.equal(y1, y2)
+    m.train()
+    m(None, coords, t).sum().backward()
+    assert all(p.grad is not None for p in m.parameters())
+    assert any(p.grad.abs().sum().item() > 0 for p in m.delta_params)
+    pen = m.compute_sparsity_penalty('sparse_group', 0.01, 0.01)
+    assert torch.isfinite(pen['total_penalty'])
+    # single quantile: the flag is ignored, standard head (reference :668)
+    m1 = STInterpMLP(k_spatial_centers=[9], k_temporal_centers=[5], hidden_dims=[32, 16], output_dim=1,
+                     use_delta_reparameterization=True)
+    assert m1.mlp_trunk is None and m1.delta_params is None and m1.get_delta_parameters() is None
+    m2 = create_model({'regression_type': 'multi-quantile', 'quantile_levels': [0.05, 0.25, 0.5, 0.75, 0.95],
+                       'use_delta_reparameterization': True, 'k_spatial_centers': [9],
+                       'k_temporal_centers': [5], 'hidden_dims': [32, 16]})
+    assert m2.use_delta_reparameterization and m2.output_dim == 5 and len(m2.delta_params) == 5

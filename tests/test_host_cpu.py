@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(handle, sym), f"{sym} declared in stdadk.h but not exported"
     assert declared == set(N.exported_symbols()), declared ^ set(N.exported_symbols())
-    assert N.lib().stdadk_abi_version() == 2
+    assert N.lib().stdadk_abi_version() == 3
 
 
 def test_abi_struct_layout_matches_header():
@@ -213,3 +213,35 @@ def test_device_dataset_matches_reference_sample_order():
     assert float(one.t.abs().max()) == 0.0               # T == 1 -> t = 0
     parts = ds.epoch_batches(4, shuffle=False)
     assert sum(p.numel() for p in parts) == len(ds) and parts[-1].numel() == len(ds) % 4 or len(ds) % 4 == 0
+
+
+def test_n3_host_surface():
+    """Loss descriptor layout, argument errors and the delta head's state_dict (reference
+    st_interp.py:671-686) — host side only."""
+    from stnf import _native as N
+    from stnf.models import STInterpMLP
+    # stdadk_loss_desc: int32 kind, y_cols; float tau[8], nc_weight; int32 nc_power
+    assert ctypes.sizeof(N.LossDesc) == 4 * (2 + 8 + 2)
+    ld = N.make_loss("pinball", 3, 1, [0.1, 0.5, 0.9], 0.5, 2)
+    assert (ld.kind, ld.y_cols, ld.nc_power) == (1, 1, 2) and abs(ld.tau[2] - 0.9) < 1e-7
+    with pytest.raises(ValueError, match="quantile levels"):
+        N.make_loss("pinball", 3, 1, [0.1, 0.5])
+    with pytest.raises(ValueError, match="Unsupported power"):
+        N.make_loss("pinball", 3, 1, [0.1, 0.5, 0.9], 1.0, 3)
+    with pytest.raises(ValueError):
+        N.make_loss("huber", 1)
+    for name in cases.QUANTILE_CASES:
+        cfg, _ = cases.quantile_cfg(name)
+        if cfg["layernorm"] and cfg["hidden_dims"] == [256, 256, 128] and len(cfg["k_spatial_centers"]) == 3 \
+                and cfg["k_spatial_centers"][0] > 100:
+            continue        # the C2-sized model is covered on the GPU
+        m = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"],
+                        k_temporal_centers=cfg["k_temporal_centers"], hidden_dims=cfg["hidden_dims"],
+                        dropout=0.0, layernorm=cfg["layernorm"], output_dim=cfg["output_dim"],
+                        use_delta_reparameterization=cfg["delta"])
+        keys = [k for k in m.state_dict() if k.startswith(("mlp.", "mlp_trunk.", "delta_params."))]
+        lay = cases.state_layout(cfg)
+        assert keys == [k for k, _, _ in lay]
+        assert all(tuple(m.state_dict()[k].shape) == shp for k, shp, _ in lay)
+    from stnf import losses
+    assert abs(losses.check_loss_numpy(np.array([1.0, 2.0, 3.0]), np.array([1.5, 2.5, 3.5]), 0.1) - 0.05) < 1e-15
