@@ -74,6 +74,46 @@ def quantile_cfg(name):
     return cfg, q["loss"]
 
 
+# N2 cases: learnable knots.  The knots start from the uniform grid PLUS a
+# deterministic perturbation (so movement, damping and the domain penalty are all active in the
+# single-gradient golden); `centers_init` stays the unperturbed grid, as after some training.
+LEARN_CASES = {
+    "tiny9_learn": dict(base="tiny9", seed=41, knots=dict(gradient_damping=False)),
+    "default227_learn": dict(base="default227", seed=42,          # the shipped DA-STDK settings
+                             knots=dict(gradient_damping=True, damping_threshold=0.0, damping_strength=5.0,
+                                        domain_penalty_weight=0.01, movement_penalty_weight=0.0)),
+    "default227_learn_gauss": dict(base="default227_gauss", seed=43,
+                                   knots=dict(gradient_damping=True, damping_threshold=0.02,
+                                              damping_strength=1.0, domain_penalty_weight=0.5,
+                                              movement_penalty_weight=0.1)),
+    "default227_learn_tri": dict(base="default227_tri", seed=44, knots=dict(gradient_damping=False,
+                                                                            movement_penalty_weight=0.05)),
+    "c2_b257_learn": dict(base="c2_b257", seed=45,
+                          knots=dict(gradient_damping=True, damping_threshold=0.0, damping_strength=5.0,
+                                     domain_penalty_weight=0.01)),
+}
+BASIS_LR_RATIO = 0.05        # train_st_interp.py:475
+BASIS_CLIP_RATIO = 0.1       # train_st_interp.py:703
+
+
+def learn_cfg(name):
+    q = LEARN_CASES[name]
+    cfg = dict(MODEL_CASES[q["base"]])
+    cfg.update(seed=q["seed"], learnable=True)
+    return cfg, q["knots"]
+
+
+def knot_perturbation(cfg):
+    """(d_centers (Ks,2), d_log_bw (Ks,)) float32, added to the grid knots / log-bandwidths in fp32."""
+    rs = np.random.RandomState(cfg["seed"] + 2000)
+    Ks = sum(cfg["k_spatial_centers"])
+    side0 = int(math.isqrt(cfg["k_spatial_centers"][-1]))
+    step = 1.0 / max(side0 - 1, 1)
+    dc = (0.3 * step * rs.standard_normal((Ks, 2))).astype(np.float32)
+    dlb = (0.1 * rs.standard_normal(Ks)).astype(np.float32)
+    return dc, dlb
+
+
 # Cases small enough that the fp32 reference arrays are stored next to the float64 truth.
 FULL_CASES = ["tiny9", "tiny9_ln_p3"]
 # Tensors with more elements than this are stored as digests (samples + row/col sums + norm).

@@ -315,8 +315,110 @@ def gen_n3_known_answers():
     print("n3_known_answers.npz", len(out), "arrays; P_nc =", out["ka_pnc"])
 
 
+# ---------------------------------------------------------------------------------------------
+# N2: learnable knots, driven as the batch body does (train_st_interp.py:470-483,617-621,660-672,
+# 693-712): MSE + domain/movement penalties, damping hook, per-group clipping, two-group AdamW, EMA
+# ---------------------------------------------------------------------------------------------
+def build_learn(cfg, kn):
+    model = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"],
+                        k_temporal_centers=cfg["k_temporal_centers"],
+                        hidden_dims=cfg["hidden_dims"], dropout=0.0, layernorm=cfg["layernorm"],
+                        spatial_learnable=True, spatial_init_method="uniform",
+                        spatial_basis_function=cfg["basis"], output_dim=cfg["output_dim"],
+                        gradient_damping=kn.get("gradient_damping", False),
+                        damping_threshold=kn.get("damping_threshold", 0.3),
+                        damping_strength=kn.get("damping_strength", 1.0))
+    sb = model.spatial_basis
+    dc, dlb = cases.knot_perturbation(cfg)
+    c0 = (sb.centers.detach().numpy() + dc).astype(np.float32)
+    lb0 = (sb.log_bandwidths.detach().numpy() + dlb).astype(np.float32)
+    st = cases.make_state(cfg)
+    sd = model.state_dict()
+    for k, v in st.items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v.copy())
+    sd["spatial_basis.centers"] = torch.from_numpy(c0.copy())
+    sd["spatial_basis.log_bandwidths"] = torch.from_numpy(lb0.copy())
+    model.load_state_dict(sd)
+    return model, c0, lb0
+
+
+def learn_loss(model, X, coords, t, y, kn):
+    loss = torch.nn.MSELoss()(model(X, coords, t), y)
+    if kn.get("domain_penalty_weight", 0.0) > 0:
+        loss = loss + kn["domain_penalty_weight"] * model.compute_domain_penalty()
+    if kn.get("movement_penalty_weight", 0.0) > 0:
+        loss = loss + kn["movement_penalty_weight"] * model.compute_movement_penalty()
+    return loss
+
+
+def learn_run(model, X, coords, t, y, kn):
+    model.train()
+    model.zero_grad()
+    yp = model(X, coords, t)
+    loss = learn_loss(model, X, coords, t, y, kn)
+    loss.backward()
+    return yp.detach(), loss.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+
+def learn_opt(model, X, coords, t, y, kn):
+    o = cases.OPT
+    basis_params = list(model.spatial_basis.parameters())
+    mlp_params = [p for p in model.parameters() if not any(p is bp for bp in basis_params)]
+    opt = torch.optim.AdamW([{"params": mlp_params, "lr": o["lr"]},
+                             {"params": basis_params, "lr": o["lr"] * cases.BASIS_LR_RATIO}],
+                            weight_decay=o["weight_decay"], betas=o["betas"], eps=o["eps"])
+    ema = ModelEMA(model, decay=o["ema_decay"])
+    losses = []
+    model.train()
+    for _ in range(o["steps"]):
+        opt.zero_grad()
+        loss = learn_loss(model, X, coords, t, y, kn)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(basis_params, o["grad_clip"] * cases.BASIS_CLIP_RATIO)
+        torch.nn.utils.clip_grad_norm_(mlp_params, o["grad_clip"])
+        opt.step()
+        ema.update(model)
+        losses.append(float(loss.detach()))
+    return ({n: p.detach().clone() for n, p in model.named_parameters()},
+            {n: v.detach().clone() for n, v in ema.shadow.items()}, np.array(losses, dtype=np.float64))
+
+
+def gen_learn_case(name):
+    cfg, kn = cases.learn_cfg(name)
+    X, coords, t, y = (torch.from_numpy(a) for a in cases.make_inputs(cfg))
+    d = (X.double(), coords.double(), t.double(), y.double())
+    out = {}
+    m32, c0, lb0 = build_learn(cfg, kn)
+    out["in_centers"], out["in_log_bw"] = c0, lb0           # fp32 INPUTS of the case (knot state)
+    out["in_centers_init"] = m32.spatial_basis.centers_init.numpy().copy()
+    y32, l32, g32 = learn_run(m32, X, coords, t, y, kn)
+    m64 = build_learn(cfg, kn)[0].double()
+    y64, l64, g64 = learn_run(m64, *d, kn)
+    out["y32"], out["y64"] = y32.numpy(), y64.numpy()
+    out["loss32"], out["loss64"] = np.float32(l32.item()), np.float64(l64.item())
+    out["domain_pen64"] = np.float64(m64.compute_domain_penalty().item())
+    out["movement_pen64"] = np.float64(m64.compute_movement_penalty().item())
+    for k in g64:
+        store(out, "g", k, g64[k].numpy(), g32[k].numpy(), cfg["seed"] + 7, False)
+    p32, s32, ls32 = learn_opt(build_learn(cfg, kn)[0], X, coords, t, y, kn)
+    p64, s64, ls64 = learn_opt(build_learn(cfg, kn)[0].double(), *d, kn)
+    out["opt_losses32"], out["opt_losses64"] = ls32, ls64
+    for k in p64:
+        store(out, "p", k, p64[k].numpy(), p32[k].numpy(), cfg["seed"] + 7, False)
+        store(out, "ema", k, s64[k].numpy(), s32[k].numpy(), cfg["seed"] + 7, False)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    gc = out["gerr32_rell2/spatial_basis.centers"]
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB  loss64={out['loss64']:.6f} "
+          f"domain={out['domain_pen64']:.4g} movement={out['movement_pen64']:.4g} ref fp32 err d_centers={gc:.2e}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["knots", "model", "n3"]
+    which = sys.argv[1:] or ["knots", "model", "n3", "n2"]
+    if "n2" in which:
+        for nm in cases.LEARN_CASES:
+            gen_learn_case(nm)
     if "knots" in which:
         gen_knots()
     if "model" in which:

@@ -268,3 +268,81 @@ def test_n3_oracle_optimizer_steps(name):
     for k in params:
         _digest_check(params[k], g, "p", k, cfg["seed"] + 7, 1e-8)
         _digest_check(shadow[k], g, "ema", k, cfg["seed"] + 7, 1e-8)
+
+
+# ------------------------------------------------------------------ N2 learnable knots
+def learn_params(name):
+    cfg, kn = cases.learn_cfg(name)
+    g = load(name)
+    params = dict(cases.make_state(cfg))
+    params["spatial_basis.centers"] = g["in_centers"]
+    params["spatial_basis.log_bandwidths"] = g["in_log_bw"]
+    return cfg, kn, g, params
+
+
+def test_n2_knot_gradient_is_the_derivative():
+    """knot_backward against finite differences of sum(G * phi) for each basis."""
+    rs = np.random.RandomState(9)
+    x = rs.uniform(0, 1, (40, 2))
+    c = rs.uniform(0, 1, (7, 2))
+    lb = np.log(rs.uniform(0.3, 0.6, 7))
+    G = rs.standard_normal((40, 7))
+    for basis in ("wendland", "gaussian", "triangular"):
+        f = lambda cc, ll: (G * orc.spatial_basis(x, cc, np.exp(ll), basis)).sum()      # noqa: E731
+        dc, dlb = orc.knot_backward(x, c, lb, G, basis)
+        for k, a in [(0, 0), (3, 1), (6, 0)]:
+            e = np.zeros_like(c); e[k, a] = 1e-6
+            assert abs((f(c + e, lb) - f(c - e, lb)) / 2e-6 - dc[k, a]) < 1e-5 * max(1.0, abs(dc[k, a])), basis
+        for k in (1, 5):
+            e = np.zeros_like(lb); e[k] = 1e-6
+            assert abs((f(c, lb + e) - f(c, lb - e)) / 2e-6 - dlb[k]) < 1e-5 * max(1.0, abs(dlb[k])), basis
+    # an observation exactly on a knot contributes nothing to that knot's centre gradient
+    x[0] = c[2]
+    dc1, _ = orc.knot_backward(x, c, lb, G, "triangular")
+    assert np.isfinite(dc1).all()
+
+
+@pytest.mark.parametrize("name", list(cases.LEARN_CASES))
+def test_n2_oracle_matches_reference_float64(name):
+    cfg, kn, g, params = learn_params(name)
+    X, coords, t, y = cases.make_inputs(cfg)
+    # the knot state of the case = grid knots (bit-exact with the reference) + the case's perturbation
+    c_grid, bw_grid, _ = orc.uniform_knots(cfg["k_spatial_centers"])
+    assert np.array_equal(g["in_centers_init"], c_grid)
+    dc, dlb = cases.knot_perturbation(cfg)
+    assert np.array_equal(g["in_centers"], (c_grid + dc).astype(np.float32))
+    assert np.abs(g["in_log_bw"] - (np.log(bw_grid.astype(np.float64)) + dlb)).max() < 1e-6
+    yp, loss, grads = orc.learnable_step_grads(X, coords, t, y, params, cfg, kn, g["in_centers_init"])
+    assert np.abs(yp - g["y64"]).max() < 1e-10
+    assert abs(orc.domain_penalty(params["spatial_basis.centers"])[0] - float(g["domain_pen64"])) < 1e-12
+    assert abs(orc.movement_penalty(params["spatial_basis.centers"], g["in_centers_init"])[0]
+               - float(g["movement_pen64"])) < 1e-12
+    assert abs(loss - float(g["loss64"])) < 1e-11
+    assert set(grads) == set(params)
+    for k in params:
+        _digest_check(grads[k], g, "g", k, cfg["seed"] + 7, 1e-9)
+
+
+@pytest.mark.parametrize("name", list(cases.LEARN_CASES))
+def test_n2_oracle_optimizer_steps(name):
+    cfg, kn, g, params = learn_params(name)
+    o = cases.OPT
+    X, coords, t, y = cases.make_inputs(cfg)
+    params = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v2 = {k: np.zeros_like(v) for k, v in params.items()}
+    shadow = {k: v.copy() for k, v in params.items()}
+    basis_keys = ["spatial_basis.centers", "spatial_basis.log_bandwidths"]
+    mlp_keys = [k for k in params if k not in basis_keys]
+    groups = [(mlp_keys, o["lr"], o["grad_clip"]),
+              (basis_keys, o["lr"] * cases.BASIS_LR_RATIO, o["grad_clip"] * cases.BASIS_CLIP_RATIO)]
+    losses = []
+    for s in range(1, o["steps"] + 1):
+        _, loss, grads = orc.learnable_step_grads(X, coords, t, y, params, cfg, kn, g["in_centers_init"])
+        losses.append(loss)
+        orc.adamw_ema_groups(params, grads, m, v2, shadow, s, groups, o["weight_decay"], o["betas"], o["eps"],
+                             o["ema_decay"])
+    assert np.abs(np.array(losses) - g["opt_losses64"]).max() < 1e-8
+    for k in params:
+        _digest_check(params[k], g, "p", k, cfg["seed"] + 7, 1e-8)
+        _digest_check(shadow[k], g, "ema", k, cfg["seed"] + 7, 1e-8)
