@@ -217,6 +217,9 @@ typedef struct stdadk_basis_desc {
 
 #define STDADK_FLAG_DENSE 1 /* force the materialising path                                    */
 #define STDADK_FLAG_W0_T 2  /* params->W[0] and grads->W[0] are (in,out) row-major              */
+#define STDADK_FLAG_LOG_BW 4 /* basis->s_bw holds LOG-bandwidths: learnable knots keep log(bw) as the
+                              * parameter and use exp() of it (st_interp.py:101-102,143-148); the
+                              * knots may sit anywhere, so the materialising path runs             */
 
 /* 1 when the (basis, mlp, flags) combination runs the window path, else 0. */
 int32_t stdadk_step_uses_window(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
@@ -243,6 +246,36 @@ int stdadk_backward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *m
                         const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads, int64_t B,
                         const float *dY, void *workspace, size_t workspace_bytes, uint64_t drop_seed,
                         const int32_t *step_dev, int32_t flags, stdadk_stream_t stream);
+
+/* N2  learnable knots (DA-STDK; st_interp.py:94-150, scripts/train_st_interp.py:660-672): gradients
+ * of the batch loss w.r.t. the spatial centres [Ks,2] and LOG-bandwidths [Ks], for the batch whose
+ * backward (stdadk_backward_f32 / stdadk_train_fwd_bwd_f32 with STDADK_FLAG_LOG_BW) has just left dZ
+ * of the first layer in `workspace`:
+ *   G = dZ0 . W0[:, p:p+Ks]                                  (what autograd sends into phi)
+ *   r = |x - c_k| / (exp(log_bw_k) cal);   d_c_k = sum_b G phi'(r) (-(x-c_k)/(|x-c_k| s_k)) (0 at zero
+ *   distance, as cdist's backward has it);   d_log_bw_k = sum_b G phi'(r) (-r)
+ * then, when `kt` is given, what the training driver adds on top (all per knot, fixed order):
+ *   + penalty_grad_scale * d/dc [ domain_weight  * sum (max(0,-c) + max(0,c-1))^2      (:493-526)
+ *                               + movement_weight * sum |c - centers_init|^2 ]         (:528-546)
+ *   x exp(-damping_strength * max(|c - centers_init| - damping_threshold, 0))  on d_c  (:111-141, the
+ *     gradient hook; applied after the penalties, as the hook sees the accumulated gradient)
+ *   loss_sum[0] += penalty_loss_scale * (weighted penalties)            (loss_sum may be NULL)
+ * kt == NULL gives the plain data gradient (the module-level autograd path: the hook and the
+ * penalties then stay with the caller).  coords are the batch's [B,2] again; d_centers / d_log_bw
+ * are overwritten. */
+typedef struct stdadk_knot_train {
+  const float *centers_init;   /* [Ks,2] device; required for damping / movement               */
+  int32_t gradient_damping;    /* 0 / 1                                                         */
+  float damping_threshold, damping_strength;
+  float domain_weight, movement_weight;
+  float penalty_grad_scale;    /* 1, or 1/world_size when the ranks' gradients are summed       */
+  float penalty_loss_scale;    /* rows*Q of this rank's batch: loss_sum is in those units        */
+} stdadk_knot_train;
+int stdadk_knot_backward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                             const stdadk_mlp_tensors *params, const float *coords, int64_t B,
+                             void *workspace, size_t workspace_bytes, int32_t flags,
+                             const stdadk_knot_train *kt, float *d_centers, float *d_log_bw,
+                             float *loss_sum, stdadk_stream_t stream);
 
 /* A2-A8 in one call: training forward, the batch objective and its gradient, backward:
  *   loss == NULL (nn.MSELoss): loss_sum[0] += sum((y_pred-y)^2), grads = d/dparams of

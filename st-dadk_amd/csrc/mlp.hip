@@ -12,6 +12,7 @@
 #include "gemm_f32.h"
 #include "window.h"
 #include "tail.h"
+#include "knots.h"
 
 #include <stdlib.h>
 
@@ -42,6 +43,7 @@ struct Plan {
   size_t wT[STDADK_MAX_HIDDEN];                              // fused tail: W_l^T scratch (l >= 1)
   // step-level buffers
   size_t feats; int64_t ldf;           // dense: materialised features
+  size_t bw_exp, kpart; int kslabs;    // learnable knots: exp(log_bw) [Ks], per-slab knot partials
   size_t psi; int ld_psi;              // window: temporal basis [B][ld_psi]
   size_t ypred, dY;                    // [B*Q]
   size_t keys, hist, cursor, cell_start, perm_tmp, perm, xs, ys, ts, y_s, X_s;
@@ -50,7 +52,7 @@ struct Plan {
 };
 
 static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = PLAN_MLP, int p_cov = 0,
-                      int Kt = 0) {
+                      int Kt = 0, int64_t Ks_learn = 0) {
   p->L = d->n_hidden;
   p->B = B;
   size_t off = 0;
@@ -74,7 +76,7 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
       s = gemm_slab_floats(h, prev, (int)B); slab = s > slab ? s : slab;          // dW  (M=h)
       s = gemm_slab_floats(prev, h, (int)B); slab = s > slab ? s : slab;          // dW^T (layer 0, W0 transposed)
     }
-    if (l > 0) { s = gemm_slab_floats((int)B, prev, h); slab = s > slab ? s : slab; }  // dA
+    if (l > 0 || Ks_learn > 0) { s = gemm_slab_floats((int)B, prev, h); slab = s > slab ? s : slab; }  // dA (layer 0: dFeat, learnable knots)
     prev = h;
   }
   {
@@ -129,6 +131,12 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
   if (mode == PLAN_STEP_DENSE) {
     p->ldf = (int64_t)align_up((size_t)d->in_dim, 32);
     p->feats = take((size_t)B * p->ldf);
+  }
+  p->bw_exp = p->kpart = 0; p->kslabs = 0;
+  if (mode == PLAN_STEP_DENSE && Ks_learn > 0) {
+    p->kslabs = knot_slabs(B);
+    p->bw_exp = take((size_t)Ks_learn);
+    p->kpart = take((size_t)p->kslabs * 3 * (size_t)Ks_learn);
   }
   if (mode == PLAN_STEP_WINDOW) {
     p->G = pick_cell_grid(B);
@@ -470,6 +478,7 @@ struct Ctx {
   float *mse_dY = nullptr;
   float *mse_loss = nullptr;
   bool mse_done = false;        // set by run_forward when the loss was fused into the tail kernel
+  bool log_bw = false;          // basis->s_bw holds log-bandwidths (learnable knots)
   LossDev loss = {STDADK_LOSS_MSE, 0, {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f}, 0.f, 1};   // y_cols 0 = Q
   const float *dz0 = nullptr;   // set by run_backward: dZ of layer 0
   // optional second stream: independent kernels of a step fork onto it (hipGraph-capturable
@@ -822,8 +831,12 @@ static int check_basis(const stdadk_basis_desc *b, const stdadk_mlp_desc *d) {
   return 0;
 }
 
+static inline int64_t learn_ks(const stdadk_basis_desc *b, int flags) {
+  return (flags & STDADK_FLAG_LOG_BW) ? b->Ks : 0;
+}
+
 static bool want_window(const stdadk_basis_desc *b, const stdadk_mlp_desc *d, int flags) {
-  if (flags & STDADK_FLAG_DENSE) return false;
+  if (flags & (STDADK_FLAG_DENSE | STDADK_FLAG_LOG_BW)) return false;
   if (!(flags & STDADK_FLAG_W0_T)) return false;
   if (d->n_hidden < 1 || b->Ks <= 0 || b->Kt <= 0) return false;
   return l1_window_supported(b->n_levels, b->basis, d->hidden[0], b->p, (int)b->Kt);
@@ -949,7 +962,8 @@ extern "C" size_t stdadk_step_workspace_bytes(const stdadk_basis_desc *b, const 
                                               int32_t flags) {
   if (check_desc(d) != 0 || check_basis(b, d) != 0 || B < 0) return 0;
   Plan p;
-  make_plan(d, B > 0 ? B : 1, &p, want_window(b, d, flags) ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt);
+  make_plan(d, B > 0 ? B : 1, &p, want_window(b, d, flags) ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt,
+            learn_ks(b, flags));
   return p.total_floats * sizeof(float);
 }
 
@@ -962,7 +976,8 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
   STDADK_REQUIRE(B > 0 && B < (1ll << 31), STDADK_E_ARG, "step: bad B");
   STDADK_REQUIRE(workspace && aligned16(workspace), STDADK_E_ALIGN, "step: workspace NULL or not 16-byte aligned");
   *window = want_window(b, d, flags);
-  make_plan(d, B, &c.pl, *window ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt);
+  make_plan(d, B, &c.pl, *window ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt, learn_ks(b, flags));
+  c.log_bw = (flags & STDADK_FLAG_LOG_BW) != 0;
   STDADK_REQUIRE(workspace_bytes >= c.pl.total_floats * sizeof(float), STDADK_E_WORKSPACE,
                  "step: workspace %zu < %zu bytes", workspace_bytes, c.pl.total_floats * sizeof(float));
   c.d = d; c.ws = (float *)workspace; c.B = B;
@@ -1000,7 +1015,13 @@ static int step_forward(Ctx &c, const stdadk_basis_desc *b, bool window, const f
     if (!y_pred) return 0;
     return unpermute_rows(ws + c.pl.ypred, (const int *)(ws + c.pl.perm), (int)c.B, d->out_dim, y_pred, c.st);
   }
-  rc = stdadk_rbf_build_f32(coords, t, X, c.B, b->p, b->s_centers, b->s_bw, b->Ks, b->basis, b->t_centers,
+  const float *s_bw = b->s_bw;
+  if (c.log_bw && b->Ks > 0) {        // bandwidth = exp(log_bandwidth)  (st_interp.py:146-148)
+    rc = launch_exp(b->s_bw, b->Ks, ws + c.pl.bw_exp, c.st);
+    if (rc) return rc;
+    s_bw = ws + c.pl.bw_exp;
+  }
+  rc = stdadk_rbf_build_f32(coords, t, X, c.B, b->p, b->s_centers, s_bw, b->Ks, b->basis, b->t_centers,
                             b->t_bw, b->Kt, ws + c.pl.feats, c.pl.ldf, stream);
   if (rc) return rc;
   return run_forward(c, 0, ws + c.pl.feats, c.pl.ldf, d->in_dim, y_pred);
@@ -1090,6 +1111,57 @@ extern "C" int stdadk_backward_f32(const stdadk_basis_desc *b, const stdadk_mlp_
   STDADK_REQUIRE(P && G && dY, STDADK_E_ARG, "backward: NULL pointer");
   c.P = P; c.G = G; c.st = (hipStream_t)stream; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = step_dev;
   return step_backward(c, b, window, dY, false);
+}
+
+extern "C" int stdadk_knot_backward_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                        const stdadk_mlp_tensors *P, const float *coords, int64_t B,
+                                        void *workspace, size_t workspace_bytes, int32_t flags,
+                                        const stdadk_knot_train *kt, float *d_centers, float *d_log_bw,
+                                        float *loss_sum, stdadk_stream_t stream) {
+  if (B == 0) return 0;
+  Ctx c;
+  bool window;
+  int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
+  if (rc) return rc;
+  STDADK_REQUIRE((flags & STDADK_FLAG_LOG_BW) && !window, STDADK_E_ARG,
+                 "knot_backward: needs STDADK_FLAG_LOG_BW (learnable knots run the materialising path)");
+  STDADK_REQUIRE(P && P->W[0] && coords && d_centers && d_log_bw, STDADK_E_ARG, "knot_backward: NULL pointer");
+  STDADK_REQUIRE(b->Ks > 0 && d->n_hidden >= 1, STDADK_E_ARG, "knot_backward: no spatial knots / no hidden layer");
+  if (kt) {
+    STDADK_REQUIRE(kt->centers_init || (!kt->gradient_damping && !(kt->movement_weight > 0.f)), STDADK_E_ARG,
+                   "knot_backward: centers_init is NULL but damping / movement penalty is on");
+    STDADK_REQUIRE(kt->domain_weight >= 0.f && kt->movement_weight >= 0.f, STDADK_E_ARG,
+                   "knot_backward: negative penalty weight");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float *ws = c.ws;
+  const int H = d->hidden[0];
+  // where run_backward left dZ of layer 0 (fused tail: its per-layer buffer; generic: the shared one)
+  const float *dz0 = (tail_enabled() && tail_supported(d, 1)) ? ws + c.pl.dZl[0] : ws + c.pl.dZ;
+  // dFeat = dZ0 . W0 over ALL feature columns, into the (now free) feature buffer
+  float *dfeat = ws + c.pl.feats;
+  if (c.w0t)
+    rc = gemm_run(dz0, H, false, P->W[0], H, false, (int)B, d->in_dim, H, nullptr, dfeat, c.pl.ldf,
+                  ws + c.pl.slab, false, nullptr, st);
+  else
+    rc = gemm_run(dz0, H, false, P->W[0], d->in_dim, true, (int)B, d->in_dim, H, nullptr, dfeat, c.pl.ldf,
+                  ws + c.pl.slab, false, nullptr, st);
+  if (rc) return rc;
+  KnotGradArgs ka;
+  ka.coords = coords; ka.B = (int)B; ka.dFeat = dfeat; ka.ld = c.pl.ldf; ka.p = b->p;
+  ka.centers = b->s_centers; ka.bw = ws + c.pl.bw_exp; ka.Ks = (int)b->Ks; ka.basis = b->basis;
+  ka.part = ws + c.pl.kpart; ka.slabs = c.pl.kslabs;
+  rc = launch_knot_grad(ka, st);
+  if (rc) return rc;
+  KnotFinishArgs fa;
+  fa.part = ka.part; fa.slabs = ka.slabs; fa.Ks = ka.Ks; fa.centers = b->s_centers;
+  fa.centers_init = kt ? kt->centers_init : nullptr;
+  fa.damping = kt ? kt->gradient_damping : 0;
+  fa.thr = kt ? kt->damping_threshold : 0.f; fa.strength = kt ? kt->damping_strength : 0.f;
+  fa.dom_w = kt ? kt->domain_weight : 0.f; fa.mov_w = kt ? kt->movement_weight : 0.f;
+  fa.pen_grad_scale = kt ? kt->penalty_grad_scale : 0.f; fa.pen_loss_scale = kt ? kt->penalty_loss_scale : 0.f;
+  fa.d_centers = d_centers; fa.d_log_bw = d_log_bw; fa.loss_sum = loss_sum;
+  return launch_knot_finish(fa, st);
 }
 
 extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,

@@ -47,8 +47,16 @@ class LossDesc(C.Structure):
                 ("nc_weight", C.c_float), ("nc_power", C.c_int32)]
 
 
+class KnotTrain(C.Structure):
+    _fields_ = [("centers_init", C.c_void_p), ("gradient_damping", C.c_int32),
+                ("damping_threshold", C.c_float), ("damping_strength", C.c_float),
+                ("domain_weight", C.c_float), ("movement_weight", C.c_float),
+                ("penalty_grad_scale", C.c_float), ("penalty_loss_scale", C.c_float)]
+
+
 FLAG_DENSE = 1
 FLAG_W0_T = 2
+FLAG_LOG_BW = 4
 
 _lib = None
 
@@ -86,6 +94,10 @@ _SIGNATURES = {
     "stdadk_backward_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
                                       C.POINTER(MlpTensors), C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_uint64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "stdadk_knot_backward_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
+                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int32,
+                                           C.POINTER(KnotTrain), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     "stdadk_train_fwd_bwd_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc),
                                            C.POINTER(MlpTensors), C.POINTER(MlpTensors), C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
@@ -378,6 +390,28 @@ def train_fwd_bwd(basis, desc, params, grads, coords, t, X, y, B, grad_scale, lo
                                         _dev(step_dev, "step_dev"), flags, _stream(),
                                         aux_stream.cuda_stream if aux_stream is not None else None)
     _check(rc, "stdadk_train_fwd_bwd_f32")
+
+
+def make_knot_train(centers_init, gradient_damping=False, damping_threshold=0.3, damping_strength=1.0,
+                    domain_weight=0.0, movement_weight=0.0, penalty_grad_scale=1.0, penalty_loss_scale=0.0):
+    kt = KnotTrain()
+    kt.centers_init = _dev(centers_init, "centers_init")
+    kt.gradient_damping = 1 if gradient_damping else 0
+    kt.damping_threshold, kt.damping_strength = float(damping_threshold), float(damping_strength)
+    kt.domain_weight, kt.movement_weight = float(domain_weight), float(movement_weight)
+    kt.penalty_grad_scale, kt.penalty_loss_scale = float(penalty_grad_scale), float(penalty_loss_scale)
+    return kt
+
+
+def knot_backward(basis, desc, params, coords, B, workspace, flags, knot_train, d_centers, d_log_bw,
+                  loss_sum=None):
+    """Gradients w.r.t. the learnable knots for the batch whose backward just ran on `workspace`."""
+    rc = lib().stdadk_knot_backward_f32(C.byref(basis), C.byref(desc), C.byref(params), _dev(coords, "coords"),
+                                        B, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                        flags, C.byref(knot_train) if knot_train is not None else None,
+                                        _dev(d_centers, "d_centers"), _dev(d_log_bw, "d_log_bw"),
+                                        _dev(loss_sum, "loss_sum"), _stream())
+    _check(rc, "stdadk_knot_backward_f32")
 
 
 def gather_batch(coords, t, y, X, idx, coords_out, t_out, y_out, X_out):

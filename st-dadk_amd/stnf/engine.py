@@ -60,7 +60,8 @@ class TrainStep:
                  grad_clip=10.0, ema_decay=None, max_batch=4096, use_graph=False,
                  process_group=None, distributed=None, force_dense=False, two_streams=False,
                  loss="mse", quantile_levels=None, non_crossing_weight=0.0, non_crossing_power=1,
-                 non_crossing_lambda=0.0):
+                 non_crossing_lambda=0.0, basis_lr_ratio=0.05, basis_clip_ratio=0.1,
+                 domain_penalty_weight=0.0, movement_penalty_weight=0.0):
         self.model = model
         if loss not in ("mse", "pinball"):
             raise ValueError(f"unknown loss '{loss}'; use 'mse' or 'pinball'")
@@ -100,9 +101,29 @@ class TrainStep:
                     views.append(self.grad[o:o + k].view(p.shape[1], p.shape[0]))
                 elif n.startswith("delta_params."):
                     dviews.append(self.grad[o:o + k])
+                elif n.startswith("spatial_basis."):
+                    pass            # knot gradients come from stdadk_knot_backward_f32 (below)
                 else:
                     views.append(self.grad[o:o + k].view(p.shape))
         self.grad_views = views
+        # learnable knots (DA-STDK): their own AdamW group (lr x basis_lr_ratio) and clip norm
+        # (grad_clip x basis_clip_ratio), scripts/train_st_interp.py:470-483,698-705; the knot tensors
+        # are registered first, so they occupy the head [0, knot_end) of the flat buffers
+        self.learnable = bool(model.spatial_basis.learnable)
+        self.knot_end = 0
+        self.knot_train = None
+        if self.learnable:
+            sb = model.spatial_basis
+            (nc, oc, kc), (nl, ol, kl) = self.offsets[0], self.offsets[1]
+            assert nc == "spatial_basis.centers" and nl == "spatial_basis.log_bandwidths" and oc == 0
+            self.g_centers = self.grad[oc:oc + kc].view(sb.k, 2)
+            self.g_log_bw = self.grad[ol:ol + kl]
+            self.knot_end = self.offsets[2][1]
+            self.basis_lr = self.lr * float(basis_lr_ratio)
+            self.basis_clip = self.grad_clip * float(basis_clip_ratio)
+            self.basis_lr_dev = torch.full((1,), self.basis_lr, device=self.dev)
+            self.sumsq_basis = torch.zeros(N.SUMSQ_PARTS, device=self.dev)
+            self.domain_w, self.movement_w = float(domain_penalty_weight), float(movement_penalty_weight)
         self.d_head = self.d_delta = None
         if model._has_delta:
             # the library differentiates w.r.t. the derived output layer; dWo/dbo are scratch and
@@ -145,6 +166,14 @@ class TrainStep:
         self.lr = float(lr)
         self.lr_dev.fill_(self.lr)
 
+    def set_basis_lr(self, lr):
+        """Learning rate of the knot group: 0 while frozen, ramped after `basis_unfreeze_epoch`
+        (scripts/train_st_interp.py:582-602)."""
+        if not self.learnable:
+            raise RuntimeError("the model's knots are not learnable")
+        self.basis_lr = float(lr)
+        self.basis_lr_dev.fill_(self.basis_lr)
+
     def _enqueue(self, X, coords, t, y, B, global_rows):
         """All kernels of one step on the current stream (capturable: no sync, no allocation)."""
         st = self.state
@@ -162,15 +191,31 @@ class TrainStep:
             N.delta_head_backward(st.delta, self.d_head[0], self.d_head[1], self.nc_lambda / self.world,
                                   self.nc_lambda * B * Q, self.d_delta,
                                   self.loss_sum if self.nc_lambda != 0.0 else None)
+        if self.learnable:
+            sb = self.model.spatial_basis
+            kt = N.make_knot_train(sb.centers_init, sb.gradient_damping, sb.damping_threshold,
+                                   sb.damping_strength, self.domain_w, self.movement_w,
+                                   penalty_grad_scale=1.0 / self.world, penalty_loss_scale=float(B * Q))
+            N.knot_backward(st.basis, st.desc, st.params, coords, B, self.ws, st.flags, kt,
+                            self.g_centers, self.g_log_bw, self.loss_sum)
         if self.distributed:
             D.allreduce_gradients(self.grad, self.pg)
+        ke = self.knot_end
         if self.grad_clip > 0:
-            N.sumsq(self.grad, self.sumsq, step_inc=self.step_dev)
+            N.sumsq(self.grad[ke:], self.sumsq, step_inc=self.step_dev)
+            if ke:
+                N.sumsq(self.grad[:ke], self.sumsq_basis)
         else:
             N.step_advance(self.step_dev)
-        N.adamw_ema(self.flat, self.grad, self.m, self.v, self.ema, self.lr, self.betas, self.eps,
-                    self.wd, self.step_count + 1, max_norm=self.grad_clip, sumsq_parts=self.sumsq,
-                    ema_decay=self.ema_decay, lr_dev=self.lr_dev, step_dev=self.step_dev)
+        ema = self.ema
+        N.adamw_ema(self.flat[ke:], self.grad[ke:], self.m[ke:], self.v[ke:], ema[ke:] if ema is not None else None,
+                    self.lr, self.betas, self.eps, self.wd, self.step_count + 1, max_norm=self.grad_clip,
+                    sumsq_parts=self.sumsq, ema_decay=self.ema_decay, lr_dev=self.lr_dev, step_dev=self.step_dev)
+        if ke:
+            N.adamw_ema(self.flat[:ke], self.grad[:ke], self.m[:ke], self.v[:ke], ema[:ke] if ema is not None else None,
+                        self.basis_lr, self.betas, self.eps, self.wd, self.step_count + 1, max_norm=self.basis_clip,
+                        sumsq_parts=self.sumsq_basis, ema_decay=self.ema_decay, lr_dev=self.basis_lr_dev,
+                        step_dev=self.step_dev)
 
     def _loss_desc(self, y_cols):
         """ABI loss descriptor for targets with `y_cols` columns (None = the plain MSE fast path)."""

@@ -18,8 +18,8 @@ import torch.nn as nn
 
 from .. import _native as N
 
-_SCOPE_MSG = ("is outside the MI355X hot path built so far (fixed uniform knots; "
-              "SURVEY.md §8 'next' row N2)")
+_SCOPE_MSG = ("is outside the MI355X hot path built so far (uniform-grid initial knots; the "
+              "data-adaptive initialisers are host-side one-offs, SURVEY.md §8 out-of-scope list)")
 
 
 def _round_up(a, b):
@@ -54,16 +54,32 @@ class SpatialBasisEmbedding(nn.Module):
         else:
             raise ValueError(f"Unknown init_method: {init_method}")
         if learnable:
-            raise NotImplementedError(f"spatial_learnable=True {_SCOPE_MSG}")
-        self.register_buffer('centers', centers)
-        self.register_buffer('_bandwidths', bandwidths)
+            # free centres (the training driver penalises / damps their movement), log-bandwidths as
+            # the parameter so the bandwidth stays positive (reference :94-107)
+            self.centers = nn.Parameter(centers)
+            self.register_buffer('centers_init', centers.clone())
+            self.log_bandwidths = nn.Parameter(torch.log(bandwidths))
+            if gradient_damping:
+                self.centers.register_hook(self._gradient_damping_hook)
+        else:
+            self.register_buffer('centers', centers)
+            self.register_buffer('_bandwidths', bandwidths)
         self.k = centers.shape[0]
         # side length of every level (uniform grids): integer bookkeeping of the window path
         self.level_sides = [int(math.sqrt(k)) for k in n_centers]
 
+    def _gradient_damping_hook(self, grad):
+        """Scale the centres' gradient by exp(-strength * max(|c - c_init| - threshold, 0)) per knot
+        (reference :111-141).  TrainStep applies the same factor inside stdadk_knot_backward_f32."""
+        with torch.no_grad():
+            dist = torch.norm(self.centers - self.centers_init, dim=1, keepdim=True)
+            excess = torch.clamp(dist - self.damping_threshold, min=0.0)
+            return grad * torch.exp(-self.damping_strength * excess)
+
     @property
     def bandwidths(self):
-        return self._bandwidths
+        """Positive bandwidths: exp(log_bandwidths) when learnable (reference :143-149)."""
+        return torch.exp(self.log_bandwidths) if self.learnable else self._bandwidths
 
     def _init_uniform(self):
         """Knot table of reference :152-185: level `side x side` grid, k = ix*side + iy,
@@ -87,15 +103,24 @@ class SpatialBasisEmbedding(nn.Module):
             coords, squeeze = coords.reshape(b * n, 2), (b, n)
         coords = coords.contiguous().float()
         out = torch.empty(coords.shape[0], self.k, device=coords.device, dtype=torch.float32)
-        N.rbf_build(coords, None, None, self.centers, self._bandwidths, self.basis_function,
+        # (values only: gradients into learnable knots flow through STInterpMLP.forward)
+        N.rbf_build(coords, None, None, self.centers.detach(), self.bandwidths.detach(), self.basis_function,
                     None, None, out)
         return out.view(*squeeze, self.k) if squeeze else out
 
     def compute_domain_penalty(self, domain_bounds=(0.0, 1.0)):
-        return torch.tensor(0.0, device=self.centers.device)      # fixed knots (reference :507-508)
+        """sum of squared distances of out-of-domain centres from [lo,hi]^2 (reference :493-526)."""
+        if not self.learnable:
+            return torch.tensor(0.0, device=self.centers.device)
+        lo, hi = domain_bounds
+        viol = torch.clamp(lo - self.centers, min=0.0) + torch.clamp(self.centers - hi, min=0.0)
+        return torch.sum(viol ** 2)
 
     def compute_movement_penalty(self):
-        return torch.tensor(0.0, device=self.centers.device)      # fixed knots (reference :537-538)
+        """sum |c - c_init|^2 (reference :528-546)."""
+        if not self.learnable:
+            return torch.tensor(0.0, device=self.centers.device)
+        return torch.sum((self.centers - self.centers_init) ** 2)
 
 
 class TemporalBasisEmbedding(nn.Module):
@@ -135,12 +160,12 @@ class _StepFunction(torch.autograd.Function):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and model.dropout_p > 0) else 0
         N.forward(st.basis, st.desc, st.params, coords, t, X, B, y, ws, st.flags, training=True, seed=seed)
         ctx.model, ctx.st, ctx.seed, ctx.B = model, st, seed, B
-        ctx.save_for_backward(ws)
+        ctx.save_for_backward(ws, coords)
         return y
 
     @staticmethod
     def backward(ctx, dY):
-        (ws,) = ctx.saved_tensors
+        ws, coords = ctx.saved_tensors
         model, st = ctx.model, ctx.st
         plist = model._body_params()
         grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in plist]
@@ -161,6 +186,13 @@ class _StepFunction(torch.autograd.Function):
             dd = torch.empty(model.output_dim, model.last_hidden_dim + 1, device=dY.device)
             N.delta_head_backward(st.delta, head[0], head[1], 0.0, 0.0, dd)
             grads += list(dd.unbind(0))
+        if model.spatial_basis.learnable:
+            # plain data gradient; the damping hook on `centers` and the driver's penalty terms are
+            # applied by autograd around this function, exactly as in the reference
+            sb = model.spatial_basis
+            dc, dlb = torch.empty_like(sb.centers), torch.empty_like(sb.log_bandwidths)
+            N.knot_backward(st.basis, st.desc, st.params, coords, ctx.B, ws, st.flags, None, dc, dlb)
+            grads = [dc, dlb] + grads
         return (None, None, None, None, None) + tuple(grads)
 
 
@@ -249,7 +281,9 @@ class STInterpMLP(nn.Module):
 
     def _param_list(self):
         """Parameters in registration order == order of named_parameters()."""
-        return self._body_params() + (list(self.delta_params) if self._has_delta else [])
+        sb = self.spatial_basis
+        knots = [sb.centers, sb.log_bandwidths] if sb.learnable else []
+        return knots + self._body_params() + (list(self.delta_params) if self._has_delta else [])
 
     def _pack(self, flat_list):
         """Tensors in _body_params() order (+ the derived [Wo, bo] under the delta head) -> ABI struct."""
@@ -295,6 +329,10 @@ class STInterpMLP(nn.Module):
 
     def _basis_desc(self):
         sb, tb = self.spatial_basis, self.temporal_basis
+        if sb.learnable:
+            # free knots: no grid bookkeeping; the bandwidth slot carries log-bandwidths (FLAG_LOG_BW)
+            return N.make_basis(self.p, self.spatial_basis_function, None, sb.centers.data,
+                                sb.log_bandwidths.data, tb.centers, tb.bandwidths)
         sides = sb.level_sides if sb.init_method == 'uniform' else None
         return N.make_basis(self.p, self.spatial_basis_function, sides, sb.centers, sb._bandwidths,
                             tb.centers, tb.bandwidths)
@@ -315,10 +353,12 @@ class STInterpMLP(nn.Module):
         w0 = tensors[0]
         st.keep = None
         flags = N.FLAG_DENSE if force_dense else 0
+        if self.spatial_basis.learnable:
+            flags |= N.FLAG_LOG_BW
         if not w0.is_contiguous() and w0.t().is_contiguous():
             tensors[0] = w0.t()                                  # engine-owned (in,out) storage
             flags |= N.FLAG_W0_T
-        elif not force_dense and N.step_uses_window(st.basis, st.desc, N.FLAG_W0_T):
+        elif not force_dense and N.step_uses_window(st.basis, st.desc, flags | N.FLAG_W0_T):
             st.keep = w0.t().contiguous()
             tensors[0] = st.keep
             flags |= N.FLAG_W0_T
@@ -337,7 +377,7 @@ class STInterpMLP(nn.Module):
         if X is not None and X.numel() > 0 and self.p > 0:
             Xc = X.contiguous().float()
         N.rbf_build(coords.contiguous().float(), t.contiguous().float().view(-1), Xc,
-                    self.spatial_basis.centers, self.spatial_basis._bandwidths,
+                    self.spatial_basis.centers.detach(), self.spatial_basis.bandwidths.detach(),
                     self.spatial_basis_function, self.temporal_basis.centers,
                     self.temporal_basis.bandwidths, out)
         return out

@@ -933,3 +933,142 @@ def test_delta_model_surface():
                        'use_delta_reparameterization': True, 'k_spatial_centers': [9],
                        'k_temporal_centers': [5], 'hidden_dims': [32, 16]})
     assert m2.use_delta_reparameterization and m2.output_dim == 5 and len(m2.delta_params) == 5
+
+
+# ------------------------------------------------------------------ N2: learnable knots (DA-STDK)
+def build_learn_model(name):
+    from stnf.models import STInterpMLP
+    cfg, kn = cases.learn_cfg(name)
+    g = load(name)
+    m = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"],
+                    k_temporal_centers=cfg["k_temporal_centers"], hidden_dims=cfg["hidden_dims"],
+                    dropout=0.0, layernorm=cfg["layernorm"], spatial_learnable=True,
+                    spatial_basis_function=cfg["basis"], output_dim=cfg["output_dim"],
+                    gradient_damping=kn.get("gradient_damping", False),
+                    damping_threshold=kn.get("damping_threshold", 0.3),
+                    damping_strength=kn.get("damping_strength", 1.0))
+    sb = m.spatial_basis
+    # grid knots and log-bandwidths are bit-identical with the reference's before the perturbation
+    assert np.array_equal(sb.centers_init.numpy(), g["in_centers_init"])
+    dc, dlb = cases.knot_perturbation(cfg)
+    assert np.array_equal((sb.centers.detach().numpy() + dc).astype(np.float32), g["in_centers"])
+    # (torch.log in fp32 may differ by one ulp between host CPUs' vector paths; the case's state is loaded below)
+    assert np.abs((sb.log_bandwidths.detach().numpy() + dlb).astype(np.float32) - g["in_log_bw"]).max() <= 5e-7
+    names = [k for k, _ in m.named_parameters()]
+    assert names[:2] == ["spatial_basis.centers", "spatial_basis.log_bandwidths"]
+    st = cases.make_state(cfg)
+    assert names[2:] == list(st.keys())
+    with torch.no_grad():
+        sb.centers.copy_(torch.from_numpy(g["in_centers"]))
+        sb.log_bandwidths.copy_(torch.from_numpy(g["in_log_bw"]))
+        for (k, p) in list(m.named_parameters())[2:]:
+            p.copy_(torch.from_numpy(st[k].copy()))
+    return m.to(dev()), cfg, kn, g
+
+
+def _learn_loss(m, X, coords, t, y, kn):
+    loss = torch.nn.functional.mse_loss(m(X, coords, t), y)
+    if kn.get("domain_penalty_weight", 0.0) > 0:
+        loss = loss + kn["domain_penalty_weight"] * m.compute_domain_penalty()
+    if kn.get("movement_penalty_weight", 0.0) > 0:
+        loss = loss + kn["movement_penalty_weight"] * m.compute_movement_penalty()
+    return loss
+
+
+@pytest.mark.parametrize("name", list(cases.LEARN_CASES))
+def test_learnable_module_loop_matches_reference(name):
+    """forward + MSE + the driver's penalties + backward with learnable knots: gradients into the
+    centres (damping hook applied) and log-bandwidths against the reference's float64 golden."""
+    m, cfg, kn, g = build_learn_model(name)
+    d = dev()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    m.train()
+    yp = m(X, coords, t)
+    assert np.abs(yp.detach().cpu().numpy() - g["y64"]).max() <= TOL * max(1.0, np.abs(g["y64"]).max())
+    assert abs(m.compute_domain_penalty().item() - float(g["domain_pen64"])) <= 1e-5 * max(1e-3, float(g["domain_pen64"]))
+    assert abs(m.compute_movement_penalty().item() - float(g["movement_pen64"])) <= 1e-5 * float(g["movement_pen64"])
+    loss = _learn_loss(m, X, coords, t, y, kn)
+    assert abs(loss.item() - float(g["loss64"])) <= 2 * TOL * max(1.0, abs(float(g["loss64"])))
+    loss.backward()
+    errs = {}
+    for k, p in m.named_parameters():
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(p.shape), k
+        errs[k] = check_vs_digest(p.grad.cpu().numpy(), g, "g", k, cfg["seed"] + 7, tol=2e-5)
+    # at least as close to the truth as the reference's own fp32 run (cdist's matmul expansion) where
+    # that run is the limiting one
+    ref_err = float(g["gerr32_rell2/spatial_basis.centers"])
+    assert errs["spatial_basis.centers"] <= max(2e-5, ref_err)
+    # eval-mode values of the embedding use exp(log_bw)
+    with torch.no_grad():
+        phi = m.spatial_basis(coords)
+    truth = orc.spatial_basis(coords.cpu().numpy(), g["in_centers"], np.exp(g["in_log_bw"].astype(np.float64)),
+                              cfg["basis"])
+    assert np.abs(phi.cpu().numpy() - truth).max() <= TOL
+
+
+@pytest.mark.parametrize("name", list(cases.LEARN_CASES))
+def test_learnable_engine_steps_match_reference(name):
+    """OPT['steps'] fused steps with the knot group: own lr (x0.05), own clip (x0.1), damping and
+    penalties inside stdadk_knot_backward_f32; parameters and EMA against the float64 golden."""
+    from stnf.engine import TrainStep
+    m, cfg, kn, g = build_learn_model(name)
+    o = cases.OPT
+    d = dev()
+    m.train()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    eng = TrainStep(m, lr=o["lr"], weight_decay=o["weight_decay"], betas=o["betas"], eps=o["eps"],
+                    grad_clip=o["grad_clip"], ema_decay=o["ema_decay"], max_batch=cfg["B"],
+                    basis_lr_ratio=cases.BASIS_LR_RATIO, basis_clip_ratio=cases.BASIS_CLIP_RATIO,
+                    domain_penalty_weight=kn.get("domain_penalty_weight", 0.0),
+                    movement_penalty_weight=kn.get("movement_penalty_weight", 0.0))
+    assert eng.learnable and not eng.uses_window
+    losses = []
+    for _ in range(o["steps"]):
+        eng.step(X if cfg["p"] else None, coords, t, y)
+        losses.append(eng.mean_loss())
+    ref = g["opt_losses64"]
+    assert np.abs(np.array(losses) - ref).max() <= 5 * TOL * max(1.0, np.abs(ref).max()), (losses, ref)
+    for k, p in m.named_parameters():
+        check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=5e-5)
+    eng.swap_in_ema()
+    for k, p in m.named_parameters():
+        check_vs_digest(p.detach().cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=5e-5)
+    eng.swap_in_ema()
+    # the state_dict keeps the reference's keys and shapes for the knot tensors
+    sd = m.state_dict()
+    assert tuple(sd["spatial_basis.centers"].shape) == (m.k_spatial, 2)
+    assert tuple(sd["spatial_basis.log_bandwidths"].shape) == (m.k_spatial,)
+    assert "spatial_basis.centers_init" in sd
+
+
+def test_learnable_engine_graph_freeze_and_errors():
+    """Graph replay == eager with the knot group; basis lr 0 keeps the knots frozen (progressive
+    unfreezing, train_st_interp.py:477-478,582-602); the knot entry point refuses fixed-knot state."""
+    from stnf.engine import TrainStep
+    from stnf import _native as N
+    d = dev()
+    res = []
+    for graph in (False, True):
+        m, cfg, kn, g = build_learn_model("default227_learn")
+        m.train()
+        X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+        eng = TrainStep(m, lr=1e-3, grad_clip=10.0, ema_decay=0.99, max_batch=64, use_graph=graph,
+                        domain_penalty_weight=0.01)
+        c0 = m.spatial_basis.centers.detach().clone()
+        eng.set_basis_lr(0.0)
+        eng.step_indexed(coords, t, y, torch.arange(64, device=d))
+        wd_only = c0 * (1.0 - 0.0 * eng.wd)
+        assert torch.equal(m.spatial_basis.centers.detach(), wd_only)        # frozen: lr 0 => no move
+        eng.set_basis_lr(1e-3 * 0.05)
+        for s in range(1, 5):
+            eng.step_indexed(coords, t, y, torch.arange(64, device=d) + 16 * s)
+        assert not torch.equal(m.spatial_basis.centers.detach(), c0)
+        res.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone())
+    assert torch.equal(res[0], res[1])
+    # fixed-knot state has no knot gradient
+    m = build_model(cases.MODEL_CASES["default227"])
+    st = m._step_state(d, force_dense=True)
+    ws = torch.empty(N.step_workspace_bytes(st.basis, st.desc, 8, st.flags) // 4, device=d)
+    with pytest.raises(RuntimeError, match="STDADK_FLAG_LOG_BW"):
+        N.knot_backward(st.basis, st.desc, st.params, torch.rand(8, 2, device=d), 8, ws, st.flags, None,
+                        torch.empty(227, 2, device=d), torch.empty(227, device=d))

@@ -135,8 +135,23 @@ def test_create_model_config_mapping():
     assert m.output_dim == 1 and m.p == 2 and m.input_dim == 2 + 9 + 5
     m5 = create_model({"regression_type": "multi-quantile", "quantile_levels": [0.05, 0.25, 0.5, 0.75, 0.95]})
     assert m5.output_dim == 5 and m5.mlp[-1].out_features == 5
+    # learnable knots (reference :94-107): parameters, log-bandwidths, initial-position buffer, penalties
+    m6 = create_model({"spatial_learnable": True, "gradient_damping": True, "damping_threshold": 0.0,
+                       "damping_strength": 5.0})
+    sb = m6.spatial_basis
+    names = [k for k, _ in m6.named_parameters()]
+    assert names[:2] == ["spatial_basis.centers", "spatial_basis.log_bandwidths"]
+    assert "spatial_basis.centers_init" in m6.state_dict() and "spatial_basis._bandwidths" not in m6.state_dict()
+    assert torch.equal(sb.bandwidths.detach(), torch.exp(sb.log_bandwidths.detach()))
+    assert float(sb.compute_domain_penalty()) == 0.0 and float(sb.compute_movement_penalty()) == 0.0
+    with torch.no_grad():
+        sb.centers[0] = torch.tensor([-0.1, 1.2])
+    assert abs(float(m6.compute_domain_penalty()) - (0.01 + 0.04)) < 1e-6
+    assert abs(float(m6.compute_movement_penalty()) - (0.01 + 1.44)) < 1e-6      # knot 0 started at (0,0)
+    g = sb._gradient_damping_hook(torch.ones(sb.k, 2))
+    assert abs(float(g[0, 0]) - float(np.exp(-5.0 * np.sqrt(1.45)))) < 1e-6 and float(g[1, 0]) == 1.0
     with pytest.raises(NotImplementedError):
-        create_model({"spatial_learnable": True})
+        create_model({"spatial_init_method": "gmm"}, train_coords=np.random.rand(50, 2))
 
 
 def test_sparsity_penalty_api():
