@@ -293,6 +293,20 @@ int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *basis, const stdadk_mlp_de
                              uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
                              stdadk_stream_t stream, stdadk_stream_t aux_stream);
 
+/* A0 + A2-A8: the same step on rows idx[b] (int64, device) of device-RESIDENT observation arrays
+ * coords_all [N,2], t_all [N], X_all [N,p], y_all [N, y cols]: the window path's binning reads the
+ * rows in place, so the batch producer (scripts/train_st_interp.py:413-460,609-612) costs no launch
+ * of its own.  Window path only (STDADK_E_ARG otherwise: gather with stdadk_gather_batch_f32 and call
+ * stdadk_train_fwd_bwd_f32).  y_pred, when given, is in batch order (row b <-> idx[b]). */
+int stdadk_train_fwd_bwd_indexed_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                                     const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,
+                                     const float *coords_all, const float *t_all, const float *X_all,
+                                     const float *y_all, const int64_t *idx, int64_t B, float grad_scale,
+                                     const stdadk_loss_desc *loss, float *loss_sum, float *y_pred,
+                                     void *workspace, size_t workspace_bytes, uint64_t drop_seed,
+                                     const int32_t *step_dev, int32_t flags, stdadk_stream_t stream,
+                                     stdadk_stream_t aux_stream);
+
 /* A0  batch producer (scripts/train_st_interp.py:413-460 dataset + collate, :609-612 H2D): rows
  * idx[b] (int64) of the device-resident observation arrays into contiguous batch buffers, one launch.
  * coords [N,2], t [N], y [N,Q], X [N,p] (NULL when p == 0). */

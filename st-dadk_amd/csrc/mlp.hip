@@ -479,6 +479,7 @@ struct Ctx {
   float *mse_loss = nullptr;
   bool mse_done = false;        // set by run_forward when the loss was fused into the tail kernel
   bool log_bw = false;          // basis->s_bw holds log-bandwidths (learnable knots)
+  const int64_t *idx = nullptr; // window path: the batch is rows idx[b] of the resident observation arrays
   LossDev loss = {STDADK_LOSS_MSE, 0, {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f}, 0.f, 1};   // y_cols 0 = Q
   const float *dz0 = nullptr;   // set by run_backward: dZ of layer 0
   // optional second stream: independent kernels of a step fork onto it (hipGraph-capturable
@@ -872,7 +873,8 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
                                  const float *X, const float *y) {
   const Plan &pl = c.pl;
   BinBuffers bb = plan_bins(c.ws, pl);
-  int rc = bin_obs(coords, t, y, c.loss.y_cols ? c.loss.y_cols : c.d->out_dim, X, b->p, (int)c.B, pl.G, bb, c.st);
+  int rc = bin_obs(coords, t, y, c.loss.y_cols ? c.loss.y_cols : c.d->out_dim, X, b->p, (int)c.B, pl.G, bb, c.st,
+                   c.idx);
   if (rc) return rc;
   L1FwdArgs a;
   a.g = make_grid(b);
@@ -1164,19 +1166,23 @@ extern "C" int stdadk_knot_backward_f32(const stdadk_basis_desc *b, const stdadk
   return launch_knot_finish(fa, st);
 }
 
-extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
-                                        const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
-                                        const float *coords, const float *t, const float *X,
-                                        const float *y, int64_t B, float grad_scale,
-                                        const stdadk_loss_desc *loss, float *loss_sum,
-                                        float *y_pred, void *workspace, size_t workspace_bytes,
-                                        uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
-                                        stdadk_stream_t stream, stdadk_stream_t aux_stream) {
+static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                              const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
+                              const float *coords, const float *t, const float *X,
+                              const float *y, const int64_t *idx, int64_t B, float grad_scale,
+                              const stdadk_loss_desc *loss, float *loss_sum,
+                              float *y_pred, void *workspace, size_t workspace_bytes,
+                              uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
+                              stdadk_stream_t stream, stdadk_stream_t aux_stream) {
   if (B == 0) return 0;
   Ctx c;
   bool window;
   int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
   if (rc) return rc;
+  STDADK_REQUIRE(!idx || window, STDADK_E_ARG,
+                 "train_fwd_bwd_indexed: only the window path gathers in place; use stdadk_gather_batch_f32 + "
+                 "stdadk_train_fwd_bwd_f32 for the materialising path");
+  c.idx = idx;
   STDADK_REQUIRE(P && G && coords && t && y, STDADK_E_ARG, "train_fwd_bwd: NULL pointer");
   c.aux = (aux_stream && aux_stream != stream) ? (hipStream_t)aux_stream : nullptr;
   STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "train_fwd_bwd: X is NULL with p=%d", b->p);
@@ -1222,4 +1228,30 @@ extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk
     if (rc) return rc;
   }
   return step_backward(c, b, false, c.ws + c.pl.dY, false);
+}
+
+extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                        const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
+                                        const float *coords, const float *t, const float *X,
+                                        const float *y, int64_t B, float grad_scale,
+                                        const stdadk_loss_desc *loss, float *loss_sum,
+                                        float *y_pred, void *workspace, size_t workspace_bytes,
+                                        uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
+                                        stdadk_stream_t stream, stdadk_stream_t aux_stream) {
+  return train_fwd_bwd_impl(b, d, P, G, coords, t, X, y, nullptr, B, grad_scale, loss, loss_sum, y_pred, workspace,
+                            workspace_bytes, drop_seed, step_dev, flags, stream, aux_stream);
+}
+
+extern "C" int stdadk_train_fwd_bwd_indexed_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                                const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
+                                                const float *coords_all, const float *t_all,
+                                                const float *X_all, const float *y_all, const int64_t *idx,
+                                                int64_t B, float grad_scale, const stdadk_loss_desc *loss,
+                                                float *loss_sum, float *y_pred, void *workspace,
+                                                size_t workspace_bytes, uint64_t drop_seed,
+                                                const int32_t *step_dev, int32_t flags,
+                                                stdadk_stream_t stream, stdadk_stream_t aux_stream) {
+  STDADK_REQUIRE(idx || B == 0, STDADK_E_ARG, "train_fwd_bwd_indexed: idx is NULL");
+  return train_fwd_bwd_impl(b, d, P, G, coords_all, t_all, X_all, y_all, idx, B, grad_scale, loss, loss_sum, y_pred,
+                            workspace, workspace_bytes, drop_seed, step_dev, flags, stream, aux_stream);
 }

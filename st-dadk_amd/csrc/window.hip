@@ -34,40 +34,77 @@ __device__ __forceinline__ int cell_of(float x, float y, int G) {
   return cx * G + cy;
 }
 
-__global__ void cell_hist_kernel(const float *__restrict__ coords, int B, int G, int *__restrict__ keys,
-                                 int *__restrict__ hist) {
+// `idx` (optional): the batch is rows idx[b] of the resident arrays; perm / keys stay batch positions
+__global__ void cell_hist_kernel(const float *__restrict__ coords, const int64_t *__restrict__ idx, int B,
+                                 int G, int *__restrict__ keys, int *__restrict__ hist) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  int c = cell_of(coords[2 * b], coords[2 * b + 1], G);
+  const int64_t r = idx ? idx[b] : b;
+  int c = cell_of(coords[2 * r], coords[2 * r + 1], G);
   keys[b] = c;
   atomicAdd(&hist[c], 1);
 }
 
-// exclusive scan of n <= 65536 counters by one 1024-thread workgroup
+// exclusive scan of n counters by one 1024-thread workgroup: tiles of 4096 counters, every thread
+// one int4 (coalesced), wave-level shuffles + a 16-entry scan of the wave totals, running carry
 __global__ __launch_bounds__(1024) void cell_scan_kernel(const int *__restrict__ hist, int n,
                                                          int *__restrict__ cell_start,
-                                                         int *__restrict__ cursor) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  const int per = (n + 1023) / 1024;
-  const int i0 = tid * per, i1 = min(i0 + per, n);
-  int s = 0;
-  for (int i = i0; i < i1; ++i) s += hist[i];
-  part[tid] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    int v = tid >= o ? part[tid - o] : 0;
+                                                         int *__restrict__ cursor, int vec) {
+  __shared__ int part[2][32];
+  const bool scalar_only = !vec;                   // buffers not 16-byte aligned: scalar accesses only
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int carry = 0;
+  const int ntile = (n + 4095) / 4096;
+  int i = 4 * tid;
+  int4 v = make_int4(0, 0, 0, 0);
+  if (i + 3 < n && !scalar_only) v = *reinterpret_cast<const int4 *>(hist + i);
+  else if (i + 3 < n) v = make_int4(hist[i], hist[i + 1], hist[i + 2], hist[i + 3]);
+  else { if (i < n) v.x = hist[i]; if (i + 1 < n) v.y = hist[i + 1]; if (i + 2 < n) v.z = hist[i + 2]; }
+  for (int tile = 0; tile < ntile; ++tile) {
+    // next tile's counters in flight while this one is scanned
+    const int in = 4096 * (tile + 1) + 4 * tid;
+    int4 vn = make_int4(0, 0, 0, 0);
+    if (tile + 1 < ntile) {
+      if (in + 3 < n && !scalar_only) vn = *reinterpret_cast<const int4 *>(hist + in);
+      else if (in + 3 < n) vn = make_int4(hist[in], hist[in + 1], hist[in + 2], hist[in + 3]);
+      else { if (in < n) vn.x = hist[in]; if (in + 1 < n) vn.y = hist[in + 1]; if (in + 2 < n) vn.z = hist[in + 2]; }
+    }
+    const int s = v.x + v.y + v.z + v.w;
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    int *pp = part[tile & 1];                      // double-buffered: one barrier per tile
+    if (lane == 63) pp[wv] = incl;
     __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+    int tot = pp[lane & 15];                       // every wave scans the 16 wave totals itself
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int u = __shfl_up(tot, o, 64);
+      if ((lane & 15) >= o) tot += u;
+    }
+    const int before = wv > 0 ? __shfl(tot, wv - 1, 64) : 0;
+    const int total = __shfl(tot, 15, 64);
+    int run = carry + before + incl - s;
+    i = 4096 * tile + 4 * tid;
+    const int4 o4 = make_int4(run, run + v.x, run + v.x + v.y, run + v.x + v.y + v.z);
+    if (i + 3 < n && !scalar_only) {
+      *reinterpret_cast<int4 *>(cell_start + i) = o4;
+      *reinterpret_cast<int4 *>(cursor + i) = o4;
+    } else if (i + 3 < n) {
+      cell_start[i] = o4.x; cell_start[i + 1] = o4.y; cell_start[i + 2] = o4.z; cell_start[i + 3] = o4.w;
+      cursor[i] = o4.x; cursor[i + 1] = o4.y; cursor[i + 2] = o4.z; cursor[i + 3] = o4.w;
+    } else {
+      if (i < n) { cell_start[i] = o4.x; cursor[i] = o4.x; }
+      if (i + 1 < n) { cell_start[i + 1] = o4.y; cursor[i + 1] = o4.y; }
+      if (i + 2 < n) { cell_start[i + 2] = o4.z; cursor[i + 2] = o4.z; }
+    }
+    carry += total;
+    v = vn;
   }
-  int run = part[tid] - s;   // exclusive prefix of this thread's chunk
-  for (int i = i0; i < i1; ++i) {
-    cell_start[i] = run;
-    cursor[i] = run;
-    run += hist[i];
-  }
-  if (tid == 1023) cell_start[n] = part[1023];
+  if (tid == 0) cell_start[n] = carry;
 }
 
 __global__ void cell_scatter_kernel(const int *__restrict__ keys, int B, int *__restrict__ cursor,
@@ -82,6 +119,7 @@ __global__ void cell_scatter_kernel(const int *__restrict__ keys, int B, int *__
 // makes the permutation independent of the atomics' arrival order) and emit the sorted arrays.
 __global__ void cell_order_kernel(const int *__restrict__ cell_start, int ncell,
                                   const int *__restrict__ perm_tmp, int *__restrict__ perm,
+                                  const int64_t *__restrict__ idx,
                                   const float *__restrict__ coords, const float *__restrict__ t,
                                   const float *__restrict__ y, int Q, const float *__restrict__ X, int p,
                                   float *__restrict__ xs, float *__restrict__ ys, float *__restrict__ ts,
@@ -94,14 +132,15 @@ __global__ void cell_order_kernel(const int *__restrict__ cell_start, int ncell,
     int rank = 0;
     for (int j = s0; j < s1; ++j) rank += perm_tmp[j] < b;
     const int pos = s0 + rank;
+    const int64_t r = idx ? idx[b] : b;
     perm[pos] = b;
-    xs[pos] = coords[2 * b];
-    ys[pos] = coords[2 * b + 1];
-    if (t) ts[pos] = t[b];
+    xs[pos] = coords[2 * r];
+    ys[pos] = coords[2 * r + 1];
+    if (t) ts[pos] = t[r];
     if (y_s)
-      for (int q = 0; q < Q; ++q) y_s[(int64_t)pos * Q + q] = y[(int64_t)b * Q + q];
+      for (int q = 0; q < Q; ++q) y_s[(int64_t)pos * Q + q] = y[r * Q + q];
     if (X_s)
-      for (int q = 0; q < p; ++q) X_s[(int64_t)pos * p + q] = X[(int64_t)b * p + q];
+      for (int q = 0; q < p; ++q) X_s[(int64_t)pos * p + q] = X[r * p + q];
   }
 }
 
@@ -114,7 +153,8 @@ __global__ void zero_ints_kernel(int *__restrict__ p, int n) {
 // scatter and in-cell ordering with the counters and the unordered permutation in LDS.  Same
 // outputs, bit for bit, as the multi-kernel path.
 constexpr int SMALL_B = 8192, SMALL_G = 64;
-__global__ __launch_bounds__(1024) void bin_small_kernel(const float *__restrict__ coords,
+__global__ __launch_bounds__(1024) void bin_small_kernel(const int64_t *__restrict__ idx,
+                                                         const float *__restrict__ coords,
                                                          const float *__restrict__ t,
                                                          const float *__restrict__ y, int Q,
                                                          const float *__restrict__ X, int p, int B, int G,
@@ -137,7 +177,8 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const float *__restrict
   for (int i = 0; i < PER_T; ++i) {
     const int b = tid + 1024 * i;
     const int bc = min(b, B - 1);
-    kk[i] = cell_of(coords[2 * bc], coords[2 * bc + 1], G);     // unconditional, clamped
+    const int64_t r = idx ? idx[bc] : bc;
+    kk[i] = cell_of(coords[2 * r], coords[2 * r + 1], G);       // unconditional, clamped
   }
 #pragma unroll
   for (int i = 0; i < PER_T; ++i) {
@@ -201,26 +242,27 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const float *__restrict
   for (int i = 0; i < PER_T; ++i) {
     const int pos = tid + 1024 * i;
     const int b = pfin[min(pos, B - 1)];
-    const float cx = coords[2 * b], cy = coords[2 * b + 1];
-    const float tv = t ? t[b] : 0.f;
+    const int64_t r = idx ? idx[b] : b;
+    const float cx = coords[2 * r], cy = coords[2 * r + 1];
+    const float tv = t ? t[r] : 0.f;
     if (pos < B) {
       perm[pos] = b;
       xs[pos] = cx;
       ys[pos] = cy;
       if (t) ts[pos] = tv;
       if (y_s)
-        for (int q = 0; q < Q; ++q) y_s[(int64_t)pos * Q + q] = y[(int64_t)b * Q + q];
+        for (int q = 0; q < Q; ++q) y_s[(int64_t)pos * Q + q] = y[r * Q + q];
       if (X_s)
-        for (int q = 0; q < p; ++q) X_s[(int64_t)pos * p + q] = X[(int64_t)b * p + q];
+        for (int q = 0; q < p; ++q) X_s[(int64_t)pos * p + q] = X[r * p + q];
     }
   }
 }
 
 int bin_obs(const float *coords, const float *t, const float *y, int Q, const float *X, int p, int B,
-            int G, const BinBuffers &bb, hipStream_t st) {
+            int G, const BinBuffers &bb, hipStream_t st, const int64_t *idx) {
   const int ncell = G * G;
   if (B <= SMALL_B && G <= SMALL_G) {
-    STDADK_LAUNCH(bin_small_kernel, dim3(1), dim3(1024), 0, st, coords, t, y, Q, X, p, B, G, bb.keys,
+    STDADK_LAUNCH(bin_small_kernel, dim3(1), dim3(1024), 0, st, idx, coords, t, y, Q, X, p, B, G, bb.keys,
                   bb.cell_start, bb.perm, bb.xs, bb.ys, bb.ts, y ? bb.y_s : (float *)nullptr,
                   (X && p > 0) ? bb.X_s : (float *)nullptr);
     STDADK_CHECK_LAUNCH("bin_obs");
@@ -229,11 +271,12 @@ int bin_obs(const float *coords, const float *t, const float *y, int Q, const fl
   // a kernel, not hipMemsetAsync: the step must stay a pure chain of kernel nodes under capture
   STDADK_LAUNCH(zero_ints_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st, bb.hist, ncell);
   const unsigned nb = (unsigned)ceil_div(B, 256);
-  STDADK_LAUNCH(cell_hist_kernel, dim3(nb), dim3(256), 0, st, coords, B, G, bb.keys, bb.hist);
-  STDADK_LAUNCH(cell_scan_kernel, dim3(1), dim3(1024), 0, st, bb.hist, ncell, bb.cell_start, bb.cursor);
+  STDADK_LAUNCH(cell_hist_kernel, dim3(nb), dim3(256), 0, st, coords, idx, B, G, bb.keys, bb.hist);
+  STDADK_LAUNCH(cell_scan_kernel, dim3(1), dim3(1024), 0, st, bb.hist, ncell, bb.cell_start, bb.cursor,
+                (aligned16(bb.hist) && aligned16(bb.cell_start) && aligned16(bb.cursor)) ? 1 : 0);
   STDADK_LAUNCH(cell_scatter_kernel, dim3(nb), dim3(256), 0, st, bb.keys, B, bb.cursor, bb.perm_tmp);
   STDADK_LAUNCH(cell_order_kernel, dim3((unsigned)ceil_div(ncell, 128)), dim3(128), 0, st, bb.cell_start,
-                ncell, bb.perm_tmp, bb.perm, coords, t, y, Q, X, p, bb.xs, bb.ys, bb.ts,
+                ncell, bb.perm_tmp, bb.perm, idx, coords, t, y, Q, X, p, bb.xs, bb.ys, bb.ts,
                 y ? bb.y_s : (float *)nullptr, (X && p > 0) ? bb.X_s : (float *)nullptr);
   STDADK_CHECK_LAUNCH("bin_obs");
   return 0;

@@ -104,6 +104,12 @@ _SIGNATURES = {
                                            C.POINTER(LossDesc),
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "stdadk_train_fwd_bwd_indexed_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc),
+                                                   C.POINTER(MlpTensors), C.POINTER(MlpTensors), C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                   C.c_float, C.POINTER(LossDesc), C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_int32,
+                                                   C.c_void_p, C.c_void_p]),
     "stdadk_gather_batch_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -390,6 +396,22 @@ def train_fwd_bwd(basis, desc, params, grads, coords, t, X, y, B, grad_scale, lo
                                         _dev(step_dev, "step_dev"), flags, _stream(),
                                         aux_stream.cuda_stream if aux_stream is not None else None)
     _check(rc, "stdadk_train_fwd_bwd_f32")
+
+
+def train_fwd_bwd_indexed(basis, desc, params, grads, coords_all, t_all, X_all, y_all, idx, grad_scale,
+                          loss_sum, y_pred, workspace, flags, seed=0, step_dev=None, aux_stream=None,
+                          loss_desc=None):
+    """The fused step on rows `idx` (contiguous int64 device tensor) of the resident arrays (window path)."""
+    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+        raise RuntimeError("train_fwd_bwd_indexed: idx must be a contiguous int64 tensor on the device")
+    rc = lib().stdadk_train_fwd_bwd_indexed_f32(
+        C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads), _dev(coords_all, "coords"),
+        _dev(t_all, "t"), _dev(X_all, "X"), _dev(y_all, "y"), idx.data_ptr(), idx.numel(), grad_scale,
+        C.byref(loss_desc) if loss_desc is not None else None, _dev(loss_sum, "loss_sum"),
+        _dev(y_pred, "y_pred"), workspace.data_ptr(), workspace.numel() * workspace.element_size(), seed,
+        _dev(step_dev, "step_dev"), flags, _stream(),
+        aux_stream.cuda_stream if aux_stream is not None else None)
+    _check(rc, "stdadk_train_fwd_bwd_indexed_f32")
 
 
 def make_knot_train(centers_init, gradient_damping=False, damping_threshold=0.3, damping_strength=1.0,

@@ -21,6 +21,13 @@ from . import _native as N
 from . import distributed as D
 
 
+# Batches up to this size are binned by ONE workgroup (window.hip: SMALL_B); random row reads from a
+# single CU are slow, so there a separate many-workgroup gather launch first is faster (MI355X, C2,
+# B = 4096: 0.185 ms/step gathered first vs 0.197 ms reading in place); above it the multi-kernel binning
+# spreads the reads over the chip and reading in place saves the gather launch.
+_INDEXED_MIN_B = 8192
+
+
 def flatten_parameters(model, transpose_first=True):
     """Move every trainable parameter of `model` into one flat fp32 buffer (the parameters become
     views, so state_dict()/checkpoints keep their names and shapes).  Each parameter is padded to a
@@ -174,17 +181,24 @@ class TrainStep:
         self.basis_lr = float(lr)
         self.basis_lr_dev.fill_(self.basis_lr)
 
-    def _enqueue(self, X, coords, t, y, B, global_rows):
-        """All kernels of one step on the current stream (capturable: no sync, no allocation)."""
+    def _enqueue(self, X, coords, t, y, B, global_rows, idx=None):
+        """All kernels of one step on the current stream (capturable: no sync, no allocation).
+        With `idx` (window path) X/coords/t/y are the RESIDENT arrays and the batch is their rows idx."""
         st = self.state
         Q = self.model.output_dim
         if st.head is not None:
             N.delta_head(st.delta, st.head[0], st.head[1])          # output layer of this step's delta
         # d(mean over the GLOBAL batch)/dparams: each rank scales by 1/global_rows, the all-reduce SUMs
-        N.train_fwd_bwd(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, B,
-                        D.grad_scale(global_rows, Q), self.loss_sum, None, self.ws, st.flags,
-                        seed=self.seed, step_dev=self.step_dev, aux_stream=self.aux_stream,
-                        loss_desc=self._loss_desc(y.shape[1]))
+        if idx is not None:
+            N.train_fwd_bwd_indexed(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, idx,
+                                    D.grad_scale(global_rows, Q), self.loss_sum, None, self.ws, st.flags,
+                                    seed=self.seed, step_dev=self.step_dev, aux_stream=self.aux_stream,
+                                    loss_desc=self._loss_desc(y.shape[1]))
+        else:
+            N.train_fwd_bwd(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, B,
+                            D.grad_scale(global_rows, Q), self.loss_sum, None, self.ws, st.flags,
+                            seed=self.seed, step_dev=self.step_dev, aux_stream=self.aux_stream,
+                            loss_desc=self._loss_desc(y.shape[1]))
         if st.head is not None:
             # every rank adds 1/world of the parameter-level penalty gradient (the all-reduce SUMs);
             # the loss accumulator is in units of rows*Q like the data term
@@ -274,8 +288,12 @@ class TrainStep:
         Xa = X_all if p > 0 else None
 
         def enqueue():
-            N.gather_batch(coords_all, t_all, y_all, Xa, ib, cb, tb, yb, xb)
-            self._enqueue(xb, cb, tb, yb, B, global_rows)
+            if self.uses_window and B > _INDEXED_MIN_B:
+                # the binning kernels read rows idx of the resident arrays in place
+                self._enqueue(Xa, coords_all, t_all, y_all, B, global_rows, idx=ib)
+            else:
+                N.gather_batch(coords_all, t_all, y_all, Xa, ib, cb, tb, yb, xb)
+                self._enqueue(xb, cb, tb, yb, B, global_rows)
 
         ib.copy_(idx)
         if self.use_graph and not self.distributed:

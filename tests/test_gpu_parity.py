@@ -1072,3 +1072,33 @@ def test_learnable_engine_graph_freeze_and_errors():
     with pytest.raises(RuntimeError, match="STDADK_FLAG_LOG_BW"):
         N.knot_backward(st.basis, st.desc, st.params, torch.rand(8, 2, device=d), 8, ws, st.flags, None,
                         torch.empty(227, 2, device=d), torch.empty(227, device=d))
+
+
+@pytest.mark.parametrize("B", [9000, 70000])
+def test_indexed_step_large_batches_equals_gathered(B):
+    """Batches beyond the single-workgroup binning (multi-kernel histogram / tiled scan / scatter /
+    in-cell ordering, G up to 256): rows read in place through idx == the gathered batch, bit for bit
+    (the binning is deterministic, so both runs do the same arithmetic)."""
+    from stnf.engine import TrainStep
+    cfg = dict(cases.MODEL_CASES["default227"], p=2)
+    d = dev()
+    rs = np.random.RandomState(B)
+    n = B + 5000
+    coords = torch.from_numpy(rs.uniform(-0.05, 1.05, (n, 2)).astype(np.float32)).to(d)
+    t = torch.from_numpy(rs.uniform(0, 1, (n,)).astype(np.float32)).to(d)
+    X = torch.from_numpy(rs.standard_normal((n, 2)).astype(np.float32)).to(d)
+    y = torch.from_numpy(rs.standard_normal((n, 1)).astype(np.float32)).to(d)
+    idx = torch.from_numpy(rs.permutation(n)[:B].astype(np.int64)).to(d)
+    res = []
+    for mode in ("gathered", "indexed"):
+        m = build_model(cfg)
+        eng = TrainStep(m, ema_decay=0.99, max_batch=B)
+        assert eng.uses_window
+        for _ in range(2):
+            if mode == "gathered":
+                eng.step(X[idx], coords[idx], t[idx], y[idx])
+            else:
+                eng.step_indexed(coords, t, y, idx, X_all=X)
+        res.append((eng.mean_loss(), eng.flat.clone()))
+    assert torch.equal(res[0][1], res[1][1])
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
