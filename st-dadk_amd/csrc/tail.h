@@ -9,7 +9,7 @@
 namespace stdadk {
 
 constexpr int TAIL_MAX_LAYERS = STDADK_MAX_HIDDEN;   // hidden layers handled by one launch
-constexpr int TAIL_ROWS = 32;                        // most rows a workgroup carries (tail_rows(B) picks 16 or 32)
+constexpr int TAIL_ROWS = 64;                        // most rows a workgroup carries (tail_rows(B) picks 16, 32 or 64)
 constexpr int TAIL_MIN_ROWS = 16;
 constexpr int TAIL_MAX_W = 256;                      // widest layer the LDS plan holds
 constexpr int TAIL_MAXQ = 8;

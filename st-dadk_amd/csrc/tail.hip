@@ -313,8 +313,11 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *d0 = smem, *d1 = smem + R * ACT_LD;
-  float *red = smem + 2 * R * ACT_LD;                // [3][NW][256]
-  float *sdy = red + 3 * NW * 256;                   // [R][TAIL_MAXQ]
+  // column-partial scratch [3][NW][256]: with 64 rows the spare activation buffer is large enough and
+  // free during the LayerNorm phase, so it is aliased there instead of taking another 48 KiB
+  constexpr bool RED_ALIAS = (size_t)R * ACT_LD >= (size_t)3 * NW * 256;
+  float *red_own = smem + 2 * R * ACT_LD;
+  float *sdy = red_own + (RED_ALIAS ? 0 : 3 * NW * 256);   // [R][TAIL_MAXQ]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, c16 = lane & 15;
@@ -425,7 +428,8 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
         }
       }
     }
-    // column partials of this workgroup's 16 rows
+    // column partials of this workgroup's rows (`nxt` is not read again before the GEMM below refills it)
+    float *red = RED_ALIAS ? nxt : red_own;
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
       red[(0 * NW + wave) * 256 + lane + 64 * cc] = pg[cc];
@@ -495,11 +499,18 @@ bool tail_supported(const stdadk_mlp_desc *d, int first_layer) {
 }
 
 static size_t fwd_lds(int R) { return (size_t)(2 * R * ACT_LD) * sizeof(float); }
-static size_t bwd_lds(int R) { return (size_t)(2 * R * ACT_LD + 3 * NW * 256 + R * TAIL_MAXQ) * sizeof(float); }
+static size_t bwd_lds(int R) {
+  const bool alias = (size_t)R * ACT_LD >= (size_t)3 * NW * 256;
+  return (size_t)(2 * R * ACT_LD + (alias ? 0 : 3 * NW * 256) + R * TAIL_MAXQ) * sizeof(float);
+}
 
 int tail_rows(int64_t B) {
-  // two 16-row tiles per workgroup (shared weight fragments) once that still gives every CU a
-  // workgroup; one tile per workgroup for small batches
+  // two or four 16-row tiles per workgroup (shared weight fragments) once that still gives every CU
+  // a workgroup; one tile per workgroup for small batches
+  static const int forced = [] { const char *e = getenv("STDADK_TAIL_ROWS"); return e ? atoi(e) : 0; }();
+  if (forced == 16 || forced == 32 || forced == 64) return forced;      // measurement aid
+  // (MI355X, C2 widths: 64 rows +5 % step throughput at B = 16 384 and 65 536 over 32 rows)
+  if (ceil_div(B, 64) >= 256) return 64;
   return ceil_div(B, 32) >= 256 ? 32 : 16;
 }
 
@@ -519,7 +530,8 @@ static int launch_fwd(const TailFwdArgs &a, hipStream_t st) {
 }
 
 int tail_forward(const TailFwdArgs &a, hipStream_t st) {
-  return tail_rows(a.B) == 32 ? launch_fwd<2>(a, st) : launch_fwd<1>(a, st);
+  const int r = tail_rows(a.B);
+  return r == 64 ? launch_fwd<4>(a, st) : (r == 32 ? launch_fwd<2>(a, st) : launch_fwd<1>(a, st));
 }
 
 template <int MT>
@@ -558,7 +570,8 @@ int tail_transpose_weights(const TailBwdArgs &a, hipStream_t st) {
 }
 
 int tail_backward(const TailBwdArgs &a, hipStream_t st) {
-  return tail_rows(a.B) == 32 ? launch_bwd<2>(a, st) : launch_bwd<1>(a, st);
+  const int r = tail_rows(a.B);
+  return r == 64 ? launch_bwd<4>(a, st) : (r == 32 ? launch_bwd<2>(a, st) : launch_bwd<1>(a, st));
 }
 
 }  // namespace stdadk

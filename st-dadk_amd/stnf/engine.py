@@ -81,6 +81,7 @@ class TrainStep:
         self.nc_power = int(non_crossing_power)
         self.nc_lambda = float(non_crossing_lambda) if model._has_delta else 0.0
         self._loss_descs = {}
+        self.indexed_min_batch = _INDEXED_MIN_B
         self.dev = next(model.parameters()).device
         if self.dev.type != "cuda":
             raise RuntimeError("TrainStep needs the model on a HIP device; there is no CPU path")
@@ -288,7 +289,7 @@ class TrainStep:
         Xa = X_all if p > 0 else None
 
         def enqueue():
-            if self.uses_window and B > _INDEXED_MIN_B:
+            if self.uses_window and B > self.indexed_min_batch:
                 # the binning kernels read rows idx of the resident arrays in place
                 self._enqueue(Xa, coords_all, t_all, y_all, B, global_rows, idx=ib)
             else:

@@ -1074,7 +1074,7 @@ def test_learnable_engine_graph_freeze_and_errors():
                         torch.empty(227, 2, device=d), torch.empty(227, device=d))
 
 
-@pytest.mark.parametrize("B", [9000, 70000])
+@pytest.mark.parametrize("B", [193, 9000, 70000])
 def test_indexed_step_large_batches_equals_gathered(B):
     """Batches beyond the single-workgroup binning (multi-kernel histogram / tiled scan / scatter /
     in-cell ordering, G up to 256): rows read in place through idx == the gathered batch, bit for bit
@@ -1094,6 +1094,7 @@ def test_indexed_step_large_batches_equals_gathered(B):
         m = build_model(cfg)
         eng = TrainStep(m, ema_decay=0.99, max_batch=B)
         assert eng.uses_window
+        eng.indexed_min_batch = 0          # B = 193: the single-workgroup binning reading in place, too
         for _ in range(2):
             if mode == "gathered":
                 eng.step(X[idx], coords[idx], t[idx], y[idx])
