@@ -295,31 +295,45 @@ def main():
             "final_mean_loss": loss,
         }
         if args.gpus == 1 and not args.no_sweep:
-            # the survey's per-GPU batch sweep: same model, same step, other batch sizes
-            sweep = {}
-            for b2 in (16384, 65536):
-                if b2 == B or b2 > n_obs:
-                    continue
+            def timed(b2, k2, model_kw=None, eng_kw=None):
+                """obs/s of the same fused step for another batch size / objective / knot mode."""
                 torch.manual_seed(0)
-                m2 = STInterpMLP(p=0, k_spatial_centers=wl["k_spatial_centers"],
-                                 k_temporal_centers=wl["k_temporal_centers"], hidden_dims=wl["hidden_dims"],
-                                 dropout=args.dropout, layernorm=True).to(dev)
+                mk = dict(p=0, k_spatial_centers=wl["k_spatial_centers"],
+                          k_temporal_centers=wl["k_temporal_centers"], hidden_dims=wl["hidden_dims"],
+                          dropout=args.dropout, layernorm=True)
+                mk.update(model_kw or {})
+                m2 = STInterpMLP(**mk).to(dev)
                 m2.train()
                 e2 = TrainStep(m2, lr=2e-2, weight_decay=5e-4, grad_clip=10.0, ema_decay=0.999, max_batch=b2,
-                               use_graph=not args.no_graph)
+                               use_graph=not args.no_graph, **(eng_kw or {}))
                 nb2 = max(n_obs // b2, 1)
                 for i in range(5):
                     e2.step_indexed(coords, t, y, perm[(i % nb2) * b2:(i % nb2) * b2 + b2])
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                k2 = 40
                 for i in range(k2):
                     e2.step_indexed(coords, t, y, perm[(i % nb2) * b2:(i % nb2) * b2 + b2])
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
-                sweep[str(b2)] = {"obs_per_s": b2 * k2 / dt, "ms_per_step": dt / k2 * 1e3}
+                res = {"obs_per_s": b2 * k2 / dt, "ms_per_step": dt / k2 * 1e3,
+                       "path": "window" if e2.uses_window else "materialised"}
                 del e2, m2
-            out["batch_sweep"] = sweep
+                return res
+            # the survey's per-GPU batch sweep (SURVEY.md §8(d)): same model, same step, other batch sizes
+            out["batch_sweep"] = {str(b2): timed(b2, 40) for b2 in (16384, 65536) if b2 != B and b2 <= n_obs}
+            # the "next" rows of SURVEY.md §8(f) on the same workload and batch: multi-quantile objectives
+            # (N3) and learnable knots (N2, materialising path); reported beside, never as, `value`
+            taus = [0.05, 0.25, 0.5, 0.75, 0.95]
+            out["variants"] = {
+                "multi_quantile_q5_noncrossing": timed(B, 60, dict(output_dim=5), dict(
+                    loss="pinball", quantile_levels=taus, non_crossing_weight=0.5)),
+                "multi_quantile_q5_delta_head": timed(B, 60, dict(output_dim=5, use_delta_reparameterization=True),
+                                                      dict(loss="pinball", quantile_levels=taus,
+                                                           non_crossing_lambda=0.05)),
+                "learnable_knots": timed(B, 30, dict(spatial_learnable=True, gradient_damping=True,
+                                                     damping_threshold=0.0, damping_strength=5.0),
+                                         dict(domain_penalty_weight=0.01)),
+            }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, B, args.dropout)
         print(json.dumps(out))
