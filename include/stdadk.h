@@ -217,9 +217,14 @@ typedef struct stdadk_basis_desc {
 
 #define STDADK_FLAG_DENSE 1 /* force the materialising path                                    */
 #define STDADK_FLAG_W0_T 2  /* params->W[0] and grads->W[0] are (in,out) row-major              */
-#define STDADK_FLAG_LOG_BW 4 /* basis->s_bw holds LOG-bandwidths: learnable knots keep log(bw) as the
-                              * parameter and use exp() of it (st_interp.py:101-102,143-148); the
-                              * knots may sit anywhere, so the materialising path runs             */
+#define STDADK_FLAG_LOG_BW 4 /* learnable knots: basis->s_bw holds LOG-bandwidths (the parameter is
+                              * log(bw), used as exp() of it: st_interp.py:101-102,143-148) and the
+                              * centres may have moved off the grid.  With n_levels > 0 (the knots
+                              * STARTED as the uniform grid, knot k still indexed ix*side+iy) the
+                              * window path still applies: every step it widens the candidate
+                              * window per level to ceil(max_k (s_k + |c_k - grid_k|_inf)(side-1))
+                              * cells, which is guaranteed to contain every knot whose support
+                              * reaches an observation; n_levels == 0 runs the materialising path */
 
 /* 1 when the (basis, mlp, flags) combination runs the window path, else 0. */
 int32_t stdadk_step_uses_window(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
@@ -250,7 +255,8 @@ int stdadk_backward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *m
 /* N2  learnable knots (DA-STDK; st_interp.py:94-150, scripts/train_st_interp.py:660-672): gradients
  * of the batch loss w.r.t. the spatial centres [Ks,2] and LOG-bandwidths [Ks], for the batch whose
  * backward (stdadk_backward_f32 / stdadk_train_fwd_bwd_f32 with STDADK_FLAG_LOG_BW) has just left dZ
- * of the first layer in `workspace`:
+ * of the first layer (materialising path) or the raw per-knot sums (window path: the wave that owns a
+ * knot's row of dW0^T accumulates them in the same pass) in `workspace`:
  *   G = dZ0 . W0[:, p:p+Ks]                                  (what autograd sends into phi)
  *   r = |x - c_k| / (exp(log_bw_k) cal);   d_c_k = sum_b G phi'(r) (-(x-c_k)/(|x-c_k| s_k)) (0 at zero
  *   distance, as cdist's backward has it);   d_log_bw_k = sum_b G phi'(r) (-r)
@@ -261,8 +267,8 @@ int stdadk_backward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *m
  *     gradient hook; applied after the penalties, as the hook sees the accumulated gradient)
  *   loss_sum[0] += penalty_loss_scale * (weighted penalties)            (loss_sum may be NULL)
  * kt == NULL gives the plain data gradient (the module-level autograd path: the hook and the
- * penalties then stay with the caller).  coords are the batch's [B,2] again; d_centers / d_log_bw
- * are overwritten. */
+ * penalties then stay with the caller).  coords are the batch's [B,2] again (unused, may be NULL, on
+ * the window path); d_centers / d_log_bw are overwritten. */
 typedef struct stdadk_knot_train {
   const float *centers_init;   /* [Ks,2] device; required for damping / movement               */
   int32_t gradient_damping;    /* 0 / 1                                                         */

@@ -44,6 +44,7 @@ struct Plan {
   // step-level buffers
   size_t feats; int64_t ldf;           // dense: materialised features
   size_t bw_exp, kpart; int kslabs;    // learnable knots: exp(log_bw) [Ks], per-slab knot partials
+  size_t halo;                         // learnable knots, window path: per-level candidate half-widths (ints)
   size_t psi; int ld_psi;              // window: temporal basis [B][ld_psi]
   size_t ypred, dY;                    // [B*Q]
   size_t keys, hist, cursor, cell_start, perm_tmp, perm, xs, ys, ts, y_s, X_s;
@@ -132,11 +133,13 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
     p->ldf = (int64_t)align_up((size_t)d->in_dim, 32);
     p->feats = take((size_t)B * p->ldf);
   }
-  p->bw_exp = p->kpart = 0; p->kslabs = 0;
-  if (mode == PLAN_STEP_DENSE && Ks_learn > 0) {
-    p->kslabs = knot_slabs(B);
+  p->bw_exp = p->kpart = p->halo = 0; p->kslabs = 0;
+  if (mode != PLAN_MLP && Ks_learn > 0) {
+    // dense: one partial per row slab; window: the wave that owns a knot produces its whole sum
+    p->kslabs = mode == PLAN_STEP_DENSE ? knot_slabs(B) : 1;
     p->bw_exp = take((size_t)Ks_learn);
     p->kpart = take((size_t)p->kslabs * 3 * (size_t)Ks_learn);
+    p->halo = take(STDADK_MAX_LEVELS);
   }
   if (mode == PLAN_STEP_WINDOW) {
     p->G = pick_cell_grid(B);
@@ -837,7 +840,7 @@ static inline int64_t learn_ks(const stdadk_basis_desc *b, int flags) {
 }
 
 static bool want_window(const stdadk_basis_desc *b, const stdadk_mlp_desc *d, int flags) {
-  if (flags & (STDADK_FLAG_DENSE | STDADK_FLAG_LOG_BW)) return false;
+  if (flags & STDADK_FLAG_DENSE) return false;
   if (!(flags & STDADK_FLAG_W0_T)) return false;
   if (d->n_hidden < 1 || b->Ks <= 0 || b->Kt <= 0) return false;
   return l1_window_supported(b->n_levels, b->basis, d->hidden[0], b->p, (int)b->Kt);
@@ -878,6 +881,17 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
   if (rc) return rc;
   L1FwdArgs a;
   a.g = make_grid(b);
+  a.halo = nullptr;
+  if (c.log_bw) {
+    // learnable knots: bandwidth = exp(log_bandwidth) (st_interp.py:146-148), and the candidate
+    // windows follow wherever the knots are now
+    rc = launch_exp(b->s_bw, b->Ks, c.ws + pl.bw_exp, c.st);
+    if (rc) return rc;
+    a.g.bw = c.ws + pl.bw_exp;
+    rc = knot_halo(a.g, (int *)(c.ws + pl.halo), c.st);
+    if (rc) return rc;
+    a.halo = (const int *)(c.ws + pl.halo);
+  }
   a.xs = bb.xs; a.ys = bb.ys; a.ts = bb.ts; a.Xs = b->p > 0 ? bb.X_s : nullptr;
   a.B = (int)c.B; a.H = c.d->hidden[0];
   a.W0T = c.P->W[0]; a.b0 = c.P->b[0];
@@ -998,6 +1012,12 @@ static int window_dw0(Ctx &c, hipStream_t st) {
   a.cell_start = (const int *)(ws + c.pl.cell_start);
   a.G = c.pl.G; a.B = (int)c.B; a.H = c.d->hidden[0];
   a.dZ = c.dz0; a.dW0T = c.G->W[0];
+  a.W0T = nullptr; a.kpart = nullptr;
+  if (c.log_bw) {      // learnable knots: the same pass also yields the raw knot gradients
+    a.g.bw = ws + c.pl.bw_exp;
+    a.W0T = c.P->W[0];
+    a.kpart = ws + c.pl.kpart;
+  }
   return l1_window_backward(a, b->basis, st);
 }
 
@@ -1125,9 +1145,10 @@ extern "C" int stdadk_knot_backward_f32(const stdadk_basis_desc *b, const stdadk
   bool window;
   int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
   if (rc) return rc;
-  STDADK_REQUIRE((flags & STDADK_FLAG_LOG_BW) && !window, STDADK_E_ARG,
-                 "knot_backward: needs STDADK_FLAG_LOG_BW (learnable knots run the materialising path)");
-  STDADK_REQUIRE(P && P->W[0] && coords && d_centers && d_log_bw, STDADK_E_ARG, "knot_backward: NULL pointer");
+  STDADK_REQUIRE((flags & STDADK_FLAG_LOG_BW), STDADK_E_ARG,
+                 "knot_backward: needs STDADK_FLAG_LOG_BW (the state of a learnable-knot forward/backward)");
+  STDADK_REQUIRE(P && P->W[0] && (coords || window) && d_centers && d_log_bw, STDADK_E_ARG,
+                 "knot_backward: NULL pointer");
   STDADK_REQUIRE(b->Ks > 0 && d->n_hidden >= 1, STDADK_E_ARG, "knot_backward: no spatial knots / no hidden layer");
   if (kt) {
     STDADK_REQUIRE(kt->centers_init || (!kt->gradient_damping && !(kt->movement_weight > 0.f)), STDADK_E_ARG,
@@ -1138,6 +1159,16 @@ extern "C" int stdadk_knot_backward_f32(const stdadk_basis_desc *b, const stdadk
   hipStream_t st = (hipStream_t)stream;
   float *ws = c.ws;
   const int H = d->hidden[0];
+  KnotFinishArgs fa;
+  fa.part = ws + c.pl.kpart; fa.slabs = c.pl.kslabs; fa.Ks = (int)b->Ks; fa.centers = b->s_centers;
+  fa.centers_init = kt ? kt->centers_init : nullptr;
+  fa.damping = kt ? kt->gradient_damping : 0;
+  fa.thr = kt ? kt->damping_threshold : 0.f; fa.strength = kt ? kt->damping_strength : 0.f;
+  fa.dom_w = kt ? kt->domain_weight : 0.f; fa.mov_w = kt ? kt->movement_weight : 0.f;
+  fa.pen_grad_scale = kt ? kt->penalty_grad_scale : 0.f; fa.pen_loss_scale = kt ? kt->penalty_loss_scale : 0.f;
+  fa.d_centers = d_centers; fa.d_log_bw = d_log_bw; fa.loss_sum = loss_sum;
+  // window path: the per-knot gather of the backward already left the raw sums in the workspace
+  if (window) return launch_knot_finish(fa, st);
   // where run_backward left dZ of layer 0 (fused tail: its per-layer buffer; generic: the shared one)
   const float *dz0 = (tail_enabled() && tail_supported(d, 1)) ? ws + c.pl.dZl[0] : ws + c.pl.dZ;
   // dFeat = dZ0 . W0 over ALL feature columns, into the (now free) feature buffer
@@ -1155,14 +1186,6 @@ extern "C" int stdadk_knot_backward_f32(const stdadk_basis_desc *b, const stdadk
   ka.part = ws + c.pl.kpart; ka.slabs = c.pl.kslabs;
   rc = launch_knot_grad(ka, st);
   if (rc) return rc;
-  KnotFinishArgs fa;
-  fa.part = ka.part; fa.slabs = ka.slabs; fa.Ks = ka.Ks; fa.centers = b->s_centers;
-  fa.centers_init = kt ? kt->centers_init : nullptr;
-  fa.damping = kt ? kt->gradient_damping : 0;
-  fa.thr = kt ? kt->damping_threshold : 0.f; fa.strength = kt ? kt->damping_strength : 0.f;
-  fa.dom_w = kt ? kt->domain_weight : 0.f; fa.mov_w = kt ? kt->movement_weight : 0.f;
-  fa.pen_grad_scale = kt ? kt->penalty_grad_scale : 0.f; fa.pen_loss_scale = kt ? kt->penalty_loss_scale : 0.f;
-  fa.d_centers = d_centers; fa.d_log_bw = d_log_bw; fa.loss_sum = loss_sum;
   return launch_knot_finish(fa, st);
 }
 

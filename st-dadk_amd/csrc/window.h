@@ -55,6 +55,9 @@ struct L1FwdArgs {
   uint64_t seed;
   const int *step_dev;
   int rows_per_wg, n_wg;
+  // free (learnable) knots: per-level half-width R of the candidate window around the observation's
+  // grid cell, device ints written by knot_halo() every step; NULL = fixed grid knots (R = 3)
+  const int *halo;
 };
 
 // z0 = [X|phi|psi] W0 + b0 -> LN -> ReLU -> Dropout for sorted observations; also writes psi.
@@ -68,7 +71,16 @@ struct L1BwdArgs {
   int G, B, H;
   const float *dZ;      // [B][H] sorted order
   float *dW0T;          // [D][H]
+  // learnable knots: W0^T (rows p + k) and the raw knot sums [3][Ks] (d cx, d cy, d log_bw) this kernel
+  // also produces; NULL = fixed knots
+  const float *W0T;
+  float *kpart;
 };
+
+// Per level: R = ceil(max_k (s_k + |c_k - grid_k|_inf) * (side-1)), the half-width (in grid cells) of the
+// candidate window that is guaranteed to contain every knot whose support reaches an observation,
+// wherever the learnable knots have moved and however their bandwidths have changed.
+int knot_halo(const GridView &g, int *halo, hipStream_t st);
 
 // dW0T[p + k, :] = sum_b phi[b,k] dZ[b,:] for every spatial knot k (each knot row owned by one
 // wave: no atomics, summation in sorted-observation order => bitwise reproducible).

@@ -337,7 +337,7 @@ __device__ __forceinline__ void fma_row(float *acc, float s, const float *row) {
   for (int c = 0; c < CPL; ++c) acc[c] = fmaf(s, f[c], acc[c]);
 }
 
-template <int CPL, bool LN, int BASIS>
+template <int CPL, bool LN, int BASIS, bool FREE>
 __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int H = 64 * CPL;
@@ -384,12 +384,72 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) acc[c] = bias[c];
 
-    // ---- spatial levels, three at a time through the per-wave candidate list
-    for (int l0 = 0; l0 < a.g.n_levels; l0 += 3) {
+    // gather-FMA of the first `cnt` list entries (cnt a multiple of 8): 8 rows of W0^T in flight
+    auto consume = [&](int cnt) {
+      for (int e0 = 0; e0 < cnt; e0 += 8) {
+        float pv[8];
+        const float *rp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pv[e] = my_phi[e0 + e];
+          rp[e] = a.W0T + (size_t)my_k[e0 + e] * H + CPL * lane;
+        }
+        typename VecT<CPL>::T wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(rp[e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float *f = reinterpret_cast<const float *>(&wv[e]);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[c] = fmaf(pv[e], f[c], acc[c]);
+        }
+      }
+    };
+
+    // ---- spatial levels through the per-wave candidate list (fixed knots: three levels at a time,
+    // 6 x 6 candidates each; free knots: one level at a time, (2R)^2 candidates in passes of 64)
+    constexpr int LSTEP = FREE ? 1 : 3;
+    for (int l0 = 0; l0 < a.g.n_levels; l0 += LSTEP) {
       int n = 0;
-      const int l1 = min(l0 + 3, a.g.n_levels);
+      const int l1 = min(l0 + LSTEP, a.g.n_levels);
       for (int l = l0; l < l1; ++l) {
         const int side = a.g.side[l];
+        if (FREE) {
+          const int R = a.halo[l];
+          const int win = min(2 * R, side);
+          const int hi = side - win;
+          const int fx = floor_clamp(x * (float)(side - 1), side), fy = floor_clamp(y * (float)(side - 1), side);
+          const int ix0 = min(max(fx - R + 1, 0), hi), iy0 = min(max(fy - R + 1, 0), hi);
+          const int ncand = win * win;
+          for (int e0 = 0; e0 < ncand; e0 += 64) {
+            const int e = e0 + lane;
+            const int dx = e / win, dy = e - dx * win;
+            float phi = 0.f;
+            int k = 0;
+            if (e < ncand) {
+              k = a.g.off[l] + (ix0 + dx) * side + iy0 + dy;
+              phi = phi_eval<BASIS>(x, y, a.g.centers[2 * k], a.g.centers[2 * k + 1],
+                                    knot_scale(a.g.bw[k], a.g.cal));
+            }
+            const uint64_t mask = __ballot(phi != 0.f);
+            const int m = __popcll(mask);
+            if (n + m > LIST - 8) {        // list full: consume it (zero-padded to 8) and start over
+              const int npad = (n + 7) & ~7;
+              if (lane < npad - n) { my_phi[n + lane] = 0.f; my_k[n + lane] = 0; }
+              __builtin_amdgcn_wave_barrier();
+              consume(npad);
+              __builtin_amdgcn_wave_barrier();
+              n = 0;
+            }
+            if (phi != 0.f) {
+              const int pos = n + __popcll(mask & below);
+              my_phi[pos] = phi;
+              my_k[pos] = a.g.p + k;
+            }
+            n += m;
+          }
+          continue;
+        }
         const int win = side < WIN ? side : WIN;
         const int ix0 = window_start(x, side, win), iy0 = window_start(y, side, win);
         const int dx = lane / WIN, dy = lane - dx * WIN;
@@ -418,24 +478,7 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
       const int npad = (n + 7) & ~7;
       if (lane < npad - n) { my_phi[n + lane] = 0.f; my_k[n + lane] = 0; }
       __builtin_amdgcn_wave_barrier();
-      for (int e0 = 0; e0 < npad; e0 += 8) {
-        float pv[8];
-        const float *rp[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          pv[e] = my_phi[e0 + e];
-          rp[e] = a.W0T + (size_t)my_k[e0 + e] * H + CPL * lane;
-        }
-        typename VecT<CPL>::T wv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(rp[e]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float *f = reinterpret_cast<const float *>(&wv[e]);
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) acc[c] = fmaf(pv[e], f[c], acc[c]);
-        }
-      }
+      consume(npad);
       __builtin_amdgcn_wave_barrier();
     }
 
@@ -484,6 +527,38 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
   }
 }
 
+// one workgroup per level: R = ceil(max_k (s_k + |c_k - grid_k|_inf) (side-1) + eps), clamped to [1, side]
+__global__ __launch_bounds__(256) void knot_halo_kernel(GridView g, int *__restrict__ halo) {
+  const int l = blockIdx.x;
+  const int side = g.side[l], off = g.off[l];
+  const float sm1 = (float)(side > 1 ? side - 1 : 1);
+  float m = 0.f;
+  for (int j = threadIdx.x; j < side * side; j += 256) {
+    const int k = off + j;
+    const int ix = j / side, iy = j - ix * side;
+    const float gx = side > 1 ? (float)ix / sm1 : 0.f, gy = side > 1 ? (float)iy / sm1 : 0.f;
+    const float mv = fmaxf(fabsf(g.centers[2 * k] - gx), fabsf(g.centers[2 * k + 1] - gy));
+    const float v = (g.bw[k] * g.cal + mv) * sm1;
+    m = fmaxf(m, (v == v) ? v : 3.0e38f);          // NaN knots widen the window to the whole level
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float r = ceilf(m + 1e-3f);
+    halo[l] = r >= (float)side ? side : (r < 1.f ? 1 : (int)r);
+  }
+}
+
+int knot_halo(const GridView &g, int *halo, hipStream_t st) {
+  STDADK_LAUNCH(knot_halo_kernel, dim3((unsigned)g.n_levels), dim3(256), 0, st, g, halo);
+  STDADK_CHECK_LAUNCH("knot_halo");
+  return 0;
+}
+
 bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt) {
   if (n_levels <= 0 || n_levels > STDADK_MAX_LEVELS) return false;
   if (basis != STDADK_BASIS_WENDLAND && basis != STDADK_BASIS_TRIANGULAR) return false;  // compact support
@@ -493,11 +568,11 @@ bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt) {
   return true;
 }
 
-template <int CPL, bool LN, int BASIS>
-static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
+template <int CPL, bool LN, int BASIS, bool FREE>
+static int launch_fwd_t(const L1FwdArgs &a, hipStream_t st) {
   const int Kt_pad = (a.g.Kt + 3) & ~3;
   size_t lds = ((size_t)a.g.Kt * 64 * CPL + (FW_T / 64) * (LIST * 2 + Kt_pad)) * sizeof(float);
-  auto kern = l1_window_fwd_kernel<CPL, LN, BASIS>;
+  auto kern = l1_window_fwd_kernel<CPL, LN, BASIS, FREE>;
   // raise the dynamic-LDS cap when a launch needs more than any before it (never inside a stream
   // capture: the engine runs its first step eagerly)
   static size_t attr_lds = 0;
@@ -510,6 +585,11 @@ static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
   STDADK_LAUNCH_NAMED("l1_window_fwd_kernel", kern, dim3((unsigned)a.n_wg), dim3(FW_T), lds, st, a);
   STDADK_CHECK_LAUNCH("l1_window_forward");
   return 0;
+}
+
+template <int CPL, bool LN, int BASIS>
+static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
+  return a.halo ? launch_fwd_t<CPL, LN, BASIS, true>(a, st) : launch_fwd_t<CPL, LN, BASIS, false>(a, st);
 }
 
 int l1_window_forward(const L1FwdArgs &a_in, int basis, bool ln, hipStream_t st) {
@@ -541,11 +621,27 @@ int l1_window_forward(const L1FwdArgs &a_in, int basis, bool ln, hipStream_t st)
 constexpr int BW_T = 256;        // 4 waves = 4 knots per workgroup
 constexpr int BW_LIST = 64;      // compacted candidates per flush
 
-template <int CPL, int BASIS>
+// d phi / d r as autograd differentiates the forward formulas (compact-support bases of this path)
+template <int BASIS>
+__device__ __forceinline__ float basis_prime_cs(float r) {
+  if (BASIS == STDADK_BASIS_WENDLAND) {
+    if (!(r < 1.0f)) return 0.f;
+    const float om = 1.0f - r, om2 = om * om;
+    return (-56.0f / 3.0f) * r * (om2 * om2 * om) * fmaf(5.0f, r, 1.0f);
+  }
+  return r <= 1.0f ? -1.0f : 0.f;      // triangular
+}
+
+// KNOTS (learnable knots): the wave also accumulates sum_b q_b dZ[b,:] for q = the three per-pair
+// factors of d cx, d cy, d log_bw; one dot product with its W0^T row at the end turns them into the
+// knot's gradient — sum_b (dZ[b,:] . W0^T[k,:]) q_b without a reduction per pair.
+template <int CPL, int BASIS, bool KNOTS>
 __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
   constexpr int H = 64 * CPL;
+  constexpr int NQ = KNOTS ? 3 : 0;
   __shared__ float lphi[BW_T / 64][BW_LIST + 8];
   __shared__ int lidx[BW_T / 64][BW_LIST + 8];
+  __shared__ float lq[KNOTS ? 3 : 1][BW_T / 64][KNOTS ? BW_LIST + 8 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = blockIdx.x * (BW_T / 64) + wave;      // knots in table order: level 0 (coarsest) first
   if (k >= a.g.Ks) return;
@@ -564,8 +660,13 @@ __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
   const uint64_t below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
 
   float acc[CPL];
+  float qacc[KNOTS ? 3 : 1][CPL];
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+  for (int c = 0; c < CPL; ++c) {
+    acc[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < (KNOTS ? 3 : 1); ++j) qacc[j][c] = 0.f;
+  }
   int n = 0;   // entries waiting in the list (wave-uniform)
 
   auto flush = [&](int cnt) {     // cnt is a multiple of 8
@@ -582,6 +683,14 @@ __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
         const float *f = reinterpret_cast<const float *>(&wv[e]);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) acc[c] = fmaf(pv[e], f[c], acc[c]);
+        if (KNOTS) {
+#pragma unroll
+          for (int j = 0; j < NQ; ++j) {
+            const float qv = lq[j][wave][e0 + e];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) qacc[j][c] = fmaf(qv, f[c], qacc[j][c]);
+          }
+        }
       }
     }
   };
@@ -591,7 +700,20 @@ __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
     for (int base = s0; base < s1; base += 64) {
       const int i = base + lane;
       float phi = 0.f;
-      if (i < s1) phi = phi_eval<BASIS>(a.xs[i], a.ys[i], kcx, kcy, ksc);
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+      if (i < s1) {
+        if (KNOTS) {
+          const float dx = a.xs[i] - kcx, dy = a.ys[i] - kcy;
+          const float d = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+          const float rr = d * ksc;
+          phi = basis_eval<BASIS>(rr);
+          const float gp = basis_prime_cs<BASIS>(rr);
+          const float qd = d > 0.f ? gp * ksc / d : 0.f;      // cdist's backward: no pull at zero distance
+          q0 = -qd * dx; q1 = -qd * dy; q2 = -gp * rr;
+        } else {
+          phi = phi_eval<BASIS>(a.xs[i], a.ys[i], kcx, kcy, ksc);
+        }
+      }
       const uint64_t mask = __ballot(phi != 0.f);
       const int m = __popcll(mask);
       if (n + m > BW_LIST) {      // not enough room: flush the full groups of 8, keep the remainder
@@ -601,24 +723,47 @@ __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
         __builtin_amdgcn_wave_barrier();
         const int rem = n - full;
         float tp = 0.f; int ti = 0;
-        if (lane < rem) { tp = my_phi[full + lane]; ti = my_idx[full + lane]; }
+        float tq[3] = {0.f, 0.f, 0.f};
+        if (lane < rem) {
+          tp = my_phi[full + lane]; ti = my_idx[full + lane];
+          if (KNOTS) { tq[0] = lq[0][wave][full + lane]; tq[1] = lq[1][wave][full + lane]; tq[2] = lq[2][wave][full + lane]; }
+        }
         __builtin_amdgcn_wave_barrier();
-        if (lane < rem) { my_phi[lane] = tp; my_idx[lane] = ti; }
+        if (lane < rem) {
+          my_phi[lane] = tp; my_idx[lane] = ti;
+          if (KNOTS) { lq[0][wave][lane] = tq[0]; lq[1][wave][lane] = tq[1]; lq[2][wave][lane] = tq[2]; }
+        }
         n = rem;
       }
       if (phi != 0.f) {
         const int pos = n + __popcll(mask & below);
         my_phi[pos] = phi;
         my_idx[pos] = i;
+        if (KNOTS) { lq[0][wave][pos] = q0; lq[1][wave][pos] = q1; lq[2][wave][pos] = q2; }
       }
       n += m;
     }
   }
   // final flush, zero-padded to a multiple of 8 (row 0 of dZ is a valid address)
   const int npad = (n + 7) & ~7;
-  if (lane < npad - n) { my_phi[n + lane] = 0.f; my_idx[n + lane] = 0; }
+  if (lane < npad - n) {
+    my_phi[n + lane] = 0.f; my_idx[n + lane] = 0;
+    if (KNOTS) { lq[0][wave][n + lane] = 0.f; lq[1][wave][n + lane] = 0.f; lq[2][wave][n + lane] = 0.f; }
+  }
   __builtin_amdgcn_wave_barrier();
   flush(npad);
+  if (KNOTS) {
+    const typename VecT<CPL>::T wk = *reinterpret_cast<const typename VecT<CPL>::T *>(a.W0T + (size_t)(a.g.p + k) * H + CPL * lane);
+    const float *wf = reinterpret_cast<const float *>(&wk);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) s = fmaf(qacc[j][c], wf[c], s);
+      s = wave_sum(s);
+      if (lane == 0) a.kpart[(size_t)j * a.g.Ks + k] = s;
+    }
+  }
 
   typename VecT<CPL>::T o;
   float *f = reinterpret_cast<float *>(&o);
@@ -630,7 +775,14 @@ __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
 int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st) {
   STDADK_REQUIRE(a.G <= 256, STDADK_E_ARG, "l1_window_backward: G too large");
   const unsigned grid = (unsigned)ceil_div(a.g.Ks, BW_T / 64);
-#define GO(CPL_, BS_) STDADK_LAUNCH((l1_window_bwd_kernel<CPL_, BS_>), dim3(grid), dim3(BW_T), 0, st, a)
+  STDADK_REQUIRE(!a.kpart || a.W0T, STDADK_E_ARG, "l1_window_backward: knot sums need W0^T");
+#define GO(CPL_, BS_)                                                                                        \
+  do {                                                                                                       \
+    if (a.kpart) STDADK_LAUNCH_NAMED("l1_window_bwd_kernel<knots>", (l1_window_bwd_kernel<CPL_, BS_, true>), \
+                                     dim3(grid), dim3(BW_T), 0, st, a);                                      \
+    else STDADK_LAUNCH_NAMED("l1_window_bwd_kernel", (l1_window_bwd_kernel<CPL_, BS_, false>), dim3(grid),   \
+                             dim3(BW_T), 0, st, a);                                                          \
+  } while (0)
   if (a.H == 256) { if (basis == STDADK_BASIS_WENDLAND) GO(4, 0); else GO(4, 2); }
   else if (a.H == 128) { if (basis == STDADK_BASIS_WENDLAND) GO(2, 0); else GO(2, 2); }
   else { set_error("l1_window_backward: H=%d unsupported", a.H); return STDADK_E_SHAPE; }

@@ -330,8 +330,10 @@ class STInterpMLP(nn.Module):
     def _basis_desc(self):
         sb, tb = self.spatial_basis, self.temporal_basis
         if sb.learnable:
-            # free knots: no grid bookkeeping; the bandwidth slot carries log-bandwidths (FLAG_LOG_BW)
-            return N.make_basis(self.p, self.spatial_basis_function, None, sb.centers.data,
+            # the bandwidth slot carries log-bandwidths (FLAG_LOG_BW); knots that started as the uniform
+            # grid keep their grid indexing, which lets the window path follow them as they move
+            sides = sb.level_sides if sb.init_method == 'uniform' else None
+            return N.make_basis(self.p, self.spatial_basis_function, sides, sb.centers.data,
                                 sb.log_bandwidths.data, tb.centers, tb.bandwidths)
         sides = sb.level_sides if sb.init_method == 'uniform' else None
         return N.make_basis(self.p, self.spatial_basis_function, sides, sb.centers, sb._bandwidths,

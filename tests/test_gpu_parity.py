@@ -975,11 +975,14 @@ def _learn_loss(m, X, coords, t, y, kn):
     return loss
 
 
+@pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("name", list(cases.LEARN_CASES))
-def test_learnable_module_loop_matches_reference(name):
+def test_learnable_module_loop_matches_reference(name, dense):
     """forward + MSE + the driver's penalties + backward with learnable knots: gradients into the
-    centres (damping hook applied) and log-bandwidths against the reference's float64 golden."""
+    centres (damping hook applied) and log-bandwidths against the reference's float64 golden, on the
+    window path (where it applies) and on the materialising path."""
     m, cfg, kn, g = build_learn_model(name)
+    m.force_dense_path = dense
     d = dev()
     X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
     m.train()
@@ -1006,8 +1009,9 @@ def test_learnable_module_loop_matches_reference(name):
     assert np.abs(phi.cpu().numpy() - truth).max() <= TOL
 
 
+@pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("name", list(cases.LEARN_CASES))
-def test_learnable_engine_steps_match_reference(name):
+def test_learnable_engine_steps_match_reference(name, dense):
     """OPT['steps'] fused steps with the knot group: own lr (x0.05), own clip (x0.1), damping and
     penalties inside stdadk_knot_backward_f32; parameters and EMA against the float64 golden."""
     from stnf.engine import TrainStep
@@ -1020,19 +1024,22 @@ def test_learnable_engine_steps_match_reference(name):
                     grad_clip=o["grad_clip"], ema_decay=o["ema_decay"], max_batch=cfg["B"],
                     basis_lr_ratio=cases.BASIS_LR_RATIO, basis_clip_ratio=cases.BASIS_CLIP_RATIO,
                     domain_penalty_weight=kn.get("domain_penalty_weight", 0.0),
-                    movement_penalty_weight=kn.get("movement_penalty_weight", 0.0))
-    assert eng.learnable and not eng.uses_window
+                    movement_penalty_weight=kn.get("movement_penalty_weight", 0.0), force_dense=dense)
+    windowable = cfg["basis"] != "gaussian" and cfg["hidden_dims"][0] in (128, 256)
+    assert eng.learnable and eng.uses_window == (windowable and not dense)
     losses = []
     for _ in range(o["steps"]):
         eng.step(X if cfg["p"] else None, coords, t, y)
         losses.append(eng.mean_loss())
     ref = g["opt_losses64"]
     assert np.abs(np.array(losses) - ref).max() <= 5 * TOL * max(1.0, np.abs(ref).max()), (losses, ref)
+    # (Adam's m/sqrt(v) turns rounding-level differences of near-zero gradients — knot rows that few of
+    #  the 257 observations touch — into lr-sized parameter differences, hence 1e-4 after three steps)
     for k, p in m.named_parameters():
-        check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=5e-5)
+        check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=1e-4)
     eng.swap_in_ema()
     for k, p in m.named_parameters():
-        check_vs_digest(p.detach().cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=5e-5)
+        check_vs_digest(p.detach().cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=1e-4)
     eng.swap_in_ema()
     # the state_dict keeps the reference's keys and shapes for the knot tensors
     sd = m.state_dict()
@@ -1103,3 +1110,50 @@ def test_indexed_step_large_batches_equals_gathered(B):
         res.append((eng.mean_loss(), eng.flat.clone()))
     assert torch.equal(res[0][1], res[1][1])
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
+
+
+@pytest.mark.parametrize("name,move,grow", [("default227", 0.4, 1.3), ("default227_tri", 3.0, 2.2),
+                                            ("c2_b257", 1.5, 1.6), ("c2_b257", 6.0, 0.5)])
+def test_learnable_window_follows_moved_knots(name, move, grow):
+    """Knots displaced by up to `move` grid cells (finest level) and bandwidths scaled by up to `grow`:
+    the window path widens its candidate windows on the device and must agree with the materialising
+    path and with the oracle (values, dW0, knot gradients) — including overflowing candidate lists."""
+    from stnf.models import STInterpMLP
+    cfg = cases.MODEL_CASES[name]
+    d = dev()
+    rs = np.random.RandomState(int(move * 10) + 7)
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    st = cases.make_state(cfg)
+    out = {}
+    Ks = sum(cfg["k_spatial_centers"])
+    step = 1.0 / (int(np.sqrt(cfg["k_spatial_centers"][-1])) - 1)
+    dc = rs.uniform(-move * step, move * step, (Ks, 2)).astype(np.float32)
+    dlb = np.log(rs.uniform(min(1.0, grow), max(1.0, grow), Ks)).astype(np.float32)
+    for mode in ("window", "dense"):
+        m = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"],
+                        k_temporal_centers=cfg["k_temporal_centers"], hidden_dims=cfg["hidden_dims"],
+                        dropout=0.0, layernorm=cfg["layernorm"], spatial_learnable=True,
+                        spatial_basis_function=cfg["basis"])
+        with torch.no_grad():
+            m.spatial_basis.centers.add_(torch.from_numpy(dc))
+            m.spatial_basis.log_bandwidths.add_(torch.from_numpy(dlb))
+            for (k, p) in list(m.named_parameters())[2:]:
+                p.copy_(torch.from_numpy(st[k].copy()))
+        m = m.to(d)
+        m.force_dense_path = mode == "dense"
+        m.train()
+        yp = m(X, coords, t)
+        torch.nn.functional.mse_loss(yp, y).backward()
+        out[mode] = (yp.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()},
+                     m.spatial_basis.centers.detach().cpu().numpy(), m.spatial_basis.log_bandwidths.detach().cpu().numpy())
+    yw, gw, cen, lbw = out["window"]
+    yd, gd, _, _ = out["dense"]
+    params = dict(st)
+    params["spatial_basis.centers"], params["spatial_basis.log_bandwidths"] = cen, lbw
+    cinit, _, _ = orc.uniform_knots(cfg["k_spatial_centers"])
+    yo, _, go = orc.learnable_step_grads(*cases.make_inputs(cfg), params, dict(cfg), {}, cinit)
+    assert np.abs(yw - yo).max() <= TOL * max(1.0, np.abs(yo).max())
+    assert np.abs(yd - yo).max() <= TOL * max(1.0, np.abs(yo).max())
+    for k in go:
+        assert rel_l2(gw[k], go[k]) <= 2e-5, (k, "window", rel_l2(gw[k], go[k]))
+        assert rel_l2(gd[k], go[k]) <= 2e-5, (k, "dense", rel_l2(gd[k], go[k]))
