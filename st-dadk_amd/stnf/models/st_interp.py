@@ -18,8 +18,8 @@ import torch.nn as nn
 
 from .. import _native as N
 
-_SCOPE_MSG = ("is outside the MI355X hot path built so far (uniform-grid initial knots; the "
-              "data-adaptive initialisers are host-side one-offs, SURVEY.md §8 out-of-scope list)")
+_SCOPE_MSG = ("is not built: it needs the k_means_constrained package, which this image does not have "
+              "(the reference imports it lazily in the same place, st_interp.py:362)")
 
 
 def _round_up(a, b):
@@ -48,9 +48,15 @@ class SpatialBasisEmbedding(nn.Module):
                              f"Choose from {list(self.CALIBRATION_FACTORS.keys())}")
         if init_method == 'uniform':
             centers, bandwidths = self._init_uniform()
-        elif init_method in ('gmm', 'random_site', 'kmeans_balanced'):
-            assert train_coords is not None, f"train_coords required for {init_method} initialization"
-            raise NotImplementedError(f"spatial_init_method='{init_method}' {_SCOPE_MSG}")
+        elif init_method == 'gmm':
+            assert train_coords is not None, "train_coords required for GMM initialization"
+            centers, bandwidths = self._init_gmm(train_coords)
+        elif init_method == 'random_site':
+            assert train_coords is not None, "train_coords required for random_site initialization"
+            centers, bandwidths = self._init_random_site(train_coords)
+        elif init_method == 'kmeans_balanced':
+            assert train_coords is not None, "train_coords required for kmeans_balanced initialization"
+            raise NotImplementedError(f"spatial_init_method='kmeans_balanced' {_SCOPE_MSG}")
         else:
             raise ValueError(f"Unknown init_method: {init_method}")
         if learnable:
@@ -93,6 +99,50 @@ class SpatialBasisEmbedding(nn.Module):
             cs.append(torch.stack([gx.flatten(), gy.flatten()], dim=-1))
             spacing = 1.0 / (side - 1) if side > 1 else 1.0
             bs.append(torch.full((k,), 2.5 * spacing))
+        return torch.cat(cs, dim=0), torch.cat(bs, dim=0)
+
+    def _grid_bandwidth(self, k):
+        side = int(math.sqrt(k))
+        return 2.5 * (1.0 / (side - 1) if side > 1 else 1.0)
+
+    def _init_gmm(self, train_coords):
+        """Data-adaptive knots (reference :187-264), a host-side one-off: per level a spherical
+        GaussianMixture (k-means++ start, 3 restarts, 100 iterations, random_state 42) on at most
+        10 000 of the training coordinates (drawn with the global numpy RNG); knots = component means,
+        bandwidth = 4.23 * 2.5 * sigma, floored at a quarter of the same-size grid's bandwidth.
+        Scattered knots have no grid indexing, so the model runs the materialising kernels."""
+        from sklearn.mixture import GaussianMixture
+        pts = np.asarray(train_coords)
+        if len(pts) > 10000:
+            pts = pts[np.random.choice(len(pts), 10000, replace=False)]
+        pts = pts.astype(np.float64)
+        cs, bs = [], []
+        for k in self.n_centers:
+            gm = GaussianMixture(n_components=k, covariance_type='spherical', random_state=42, max_iter=100,
+                                 n_init=3, init_params='k-means++', reg_covar=1e-6, tol=1e-3, verbose=0).fit(pts)
+            bw = np.clip(4.23 * 2.5 * np.sqrt(gm.covariances_), 0.25 * self._grid_bandwidth(k), float('inf'))
+            cs.append(torch.from_numpy(gm.means_).float())
+            bs.append(torch.from_numpy(bw).float())
+        return torch.cat(cs, dim=0), torch.cat(bs, dim=0)
+
+    def _init_random_site(self, train_coords):
+        """Knots drawn from the training coordinates themselves (reference :266-343): per level k
+        rows picked with the global numpy RNG (without replacement when there are enough), bandwidth
+        = 2.5 x the mean distance to the (up to) 4 nearest other knots of the level."""
+        from scipy.spatial.distance import cdist
+        pts = np.asarray(train_coords)
+        cs, bs = [], []
+        for k in self.n_centers:
+            pick = np.random.choice(len(pts), k, replace=k > len(pts))
+            c = pts[pick]
+            dist = cdist(c, c)
+            np.fill_diagonal(dist, np.inf)
+            nn = min(4, k - 1) if k > 1 else 1
+            bw = 2.5 * np.sort(dist, axis=1)[:, :nn].mean(axis=1)
+            if k == 1:
+                bw = np.array([self._grid_bandwidth(self.n_centers[0])])
+            cs.append(torch.from_numpy(c).float())
+            bs.append(torch.from_numpy(bw).float())
         return torch.cat(cs, dim=0), torch.cat(bs, dim=0)
 
     def forward(self, coords: torch.Tensor):

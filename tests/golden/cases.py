@@ -114,6 +114,17 @@ def knot_perturbation(cfg):
     return dc, dlb
 
 
+def init_points():
+    """Clustered training coordinates for the data-adaptive initialisers (with duplicates, as the
+    driver passes them: one row per observation)."""
+    rs = np.random.RandomState(123)
+    blobs = [rs.normal(loc=c, scale=s, size=(n, 2)) for c, s, n in
+             [((0.25, 0.3), 0.06, 900), ((0.7, 0.65), 0.10, 1400), ((0.5, 0.1), 0.03, 300)]]
+    pts = np.clip(np.concatenate(blobs + [rs.uniform(0, 1, (400, 2))]), 0.0, 1.0).astype(np.float32)
+    return np.concatenate([pts, pts[:500]])
+
+
+
 # Cases small enough that the fp32 reference arrays are stored next to the float64 truth.
 FULL_CASES = ["tiny9", "tiny9_ln_p3"]
 # Tensors with more elements than this are stored as digests (samples + row/col sums + norm).

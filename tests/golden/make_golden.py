@@ -414,8 +414,28 @@ def gen_learn_case(name):
           f"domain={out['domain_pen64']:.4g} movement={out['movement_pen64']:.4g} ref fp32 err d_centers={gc:.2e}")
 
 
+def gen_init_known_answers():
+    """Knot tables of the reference's gmm / random_site initialisers (st_interp.py:187-343) on fixed
+    points with a fixed global numpy seed."""
+    out = {}
+    pts = cases.init_points()
+    for method in ("gmm", "random_site"):
+        np.random.seed(7)
+        m = SpatialBasisEmbedding(n_centers=[9, 25], init_method=method, train_coords=pts)
+        out[f"{method}_centers"] = m.centers.numpy().copy()
+        out[f"{method}_bw"] = m.bandwidths.numpy().copy()
+    np.random.seed(7)
+    big = np.concatenate([pts] * 4)                       # > 10 000 rows: the GMM subsamples
+    m = SpatialBasisEmbedding(n_centers=[16], init_method="gmm", train_coords=big)
+    out["gmm_big_centers"], out["gmm_big_bw"] = m.centers.numpy().copy(), m.bandwidths.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "init_known_answers.npz"), **out)
+    print("init_known_answers.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["knots", "model", "n3", "n2"]
+    which = sys.argv[1:] or ["knots", "model", "n3", "n2", "init"]
+    if "init" in which:
+        gen_init_known_answers()
     if "n2" in which:
         for nm in cases.LEARN_CASES:
             gen_learn_case(nm)

@@ -1157,3 +1157,35 @@ def test_learnable_window_follows_moved_knots(name, move, grow):
     for k in go:
         assert rel_l2(gw[k], go[k]) <= 2e-5, (k, "window", rel_l2(gw[k], go[k]))
         assert rel_l2(gd[k], go[k]) <= 2e-5, (k, "dense", rel_l2(gd[k], go[k]))
+
+
+@pytest.mark.parametrize("method,basis", [("random_site", "wendland"), ("gmm", "triangular")])
+def test_scattered_learnable_knots_match_oracle(method, basis):
+    """The shipped YAML's combination — data-adaptive (scattered) initial knots, learnable — runs the
+    materialising kernels (no grid indexing): values and every gradient against the oracle."""
+    from stnf.models import STInterpMLP
+    d = dev()
+    np.random.seed(11)
+    pts = cases.init_points()
+    cfg = dict(p=0, k_spatial_centers=[25, 81], k_temporal_centers=[10, 15], hidden_dims=[256, 128],
+               layernorm=True, basis=basis, output_dim=1, B=300, seed=61)
+    m = STInterpMLP(p=0, k_spatial_centers=cfg["k_spatial_centers"], k_temporal_centers=cfg["k_temporal_centers"],
+                    hidden_dims=cfg["hidden_dims"], dropout=0.0, layernorm=True, spatial_learnable=True,
+                    spatial_init_method=method, spatial_basis_function=basis, train_coords=pts)
+    st = cases.make_state(cfg)
+    with torch.no_grad():
+        for (k, p) in list(m.named_parameters())[2:]:
+            p.copy_(torch.from_numpy(st[k].copy()))
+    m = m.to(d)
+    assert m._basis_desc().n_levels == 0
+    X, coords, t, y = cases.make_inputs(cfg)
+    m.train()
+    yp = m(None, torch.from_numpy(coords).to(d), torch.from_numpy(t).to(d))
+    torch.nn.functional.mse_loss(yp, torch.from_numpy(y).to(d)).backward()
+    params = dict(st)
+    params["spatial_basis.centers"] = m.spatial_basis.centers.detach().cpu().numpy()
+    params["spatial_basis.log_bandwidths"] = m.spatial_basis.log_bandwidths.detach().cpu().numpy()
+    yo, _, go = orc.learnable_step_grads(X, coords, t, y, params, cfg, {}, params["spatial_basis.centers"])
+    assert np.abs(yp.detach().cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), go[k]) <= 2e-5, k

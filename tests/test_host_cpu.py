@@ -151,7 +151,7 @@ def test_create_model_config_mapping():
     g = sb._gradient_damping_hook(torch.ones(sb.k, 2))
     assert abs(float(g[0, 0]) - float(np.exp(-5.0 * np.sqrt(1.45)))) < 1e-6 and float(g[1, 0]) == 1.0
     with pytest.raises(NotImplementedError):
-        create_model({"spatial_init_method": "gmm"}, train_coords=np.random.rand(50, 2))
+        create_model({"spatial_init_method": "kmeans_balanced"}, train_coords=np.random.rand(50, 2))
 
 
 def test_sparsity_penalty_api():
@@ -260,3 +260,32 @@ def test_n3_host_surface():
         assert all(tuple(m.state_dict()[k].shape) == shp for k, shp, _ in lay)
     from stnf import losses
     assert abs(losses.check_loss_numpy(np.array([1.0, 2.0, 3.0]), np.array([1.5, 2.5, 3.5]), 0.1) - 0.05) < 1e-15
+
+
+def test_data_adaptive_initialisers_match_reference():
+    """gmm / random_site knot tables (host-side one-offs, reference st_interp.py:187-343) against the
+    reference's own output on the same points and numpy seed (tests/golden/make_golden.py init)."""
+    from stnf.models.st_interp import SpatialBasisEmbedding
+    from stnf.models import STInterpMLP
+    pts = cases.init_points()
+    g = np.load(os.path.join(GOLD, "init_known_answers.npz"))
+    for method in ("gmm", "random_site"):
+        np.random.seed(7)
+        m = SpatialBasisEmbedding(n_centers=[9, 25], init_method=method, train_coords=pts)
+        assert m.k == 34 and not m.learnable
+        assert np.allclose(m.centers.numpy(), g[f"{method}_centers"], rtol=0, atol=1e-6), method
+        assert np.allclose(m.bandwidths.numpy(), g[f"{method}_bw"], rtol=1e-6, atol=1e-7), method
+    np.random.seed(7)
+    m = SpatialBasisEmbedding(n_centers=[16], init_method="gmm", train_coords=np.concatenate([pts] * 4))
+    assert np.allclose(m.centers.numpy(), g["gmm_big_centers"], atol=1e-6)
+    assert np.allclose(m.bandwidths.numpy(), g["gmm_big_bw"], rtol=1e-6)
+    # the shipped YAML's combination: GMM knots, learnable, multi-quantile head
+    np.random.seed(7)
+    mm = STInterpMLP(k_spatial_centers=[9, 25], k_temporal_centers=[5], hidden_dims=[32, 16], output_dim=5,
+                     spatial_learnable=True, spatial_init_method="gmm", train_coords=pts, gradient_damping=True)
+    assert [k for k, _ in mm.named_parameters()][:2] == ["spatial_basis.centers", "spatial_basis.log_bandwidths"]
+    assert mm.spatial_basis.init_method == "gmm" and mm.spatial_basis.k == 34
+    with pytest.raises(AssertionError):
+        SpatialBasisEmbedding(n_centers=[9], init_method="gmm")
+    with pytest.raises(ValueError):
+        SpatialBasisEmbedding(n_centers=[9], init_method="bogus")
