@@ -341,6 +341,16 @@ def main():
                                                      damping_threshold=0.0, damping_strength=5.0),
                                          dict(domain_penalty_weight=0.01)),
             }
+            # the reference's SHIPPED YAML (configs/*.yaml: 227 GMM-initialised learnable knots, 5 quantiles
+            # with the delta-free head, batch 4096): scattered knots => materialising kernels
+            np.random.seed(0)
+            site = coords[:20000].cpu().numpy()
+            out["variants"]["shipped_yaml_227_gmm_learnable_mq5"] = timed(
+                B, 60, dict(k_spatial_centers=[25, 81, 121], spatial_learnable=True, spatial_init_method="gmm",
+                            train_coords=site, gradient_damping=True, damping_threshold=0.0, damping_strength=5.0,
+                            output_dim=5),
+                dict(loss="pinball", quantile_levels=taus, non_crossing_weight=0.5, domain_penalty_weight=0.01))
+            out["variants"]["ref_default_227_uniform_mse"] = timed(B, 60, dict(k_spatial_centers=[25, 81, 121]))
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, B, args.dropout)
         print(json.dumps(out))

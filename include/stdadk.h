@@ -217,6 +217,10 @@ typedef struct stdadk_basis_desc {
 
 #define STDADK_FLAG_DENSE 1 /* force the materialising path                                    */
 #define STDADK_FLAG_W0_T 2  /* params->W[0] and grads->W[0] are (in,out) row-major              */
+#define STDADK_FLAG_WINDOW 8 /* take the window path whenever it is supported, even for small knot
+                              * tables (default: tables under 1024 knots run the materialising
+                              * path, which is faster there: a coarse level's few knots each own a
+                              * large share of the batch in the per-knot gather of dW0^T)          */
 #define STDADK_FLAG_LOG_BW 4 /* learnable knots: basis->s_bw holds LOG-bandwidths (the parameter is
                               * log(bw), used as exp() of it: st_interp.py:101-102,143-148) and the
                               * centres may have moved off the grid.  With n_levels > 0 (the knots

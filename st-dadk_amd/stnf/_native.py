@@ -57,6 +57,7 @@ class KnotTrain(C.Structure):
 FLAG_DENSE = 1
 FLAG_W0_T = 2
 FLAG_LOG_BW = 4
+FLAG_WINDOW = 8
 
 _lib = None
 

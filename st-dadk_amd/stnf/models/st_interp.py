@@ -309,6 +309,8 @@ class STInterpMLP(nn.Module):
             self.delta_params = None
         # diagnostics: True forces the materialising (dense) kernels even where the window path applies
         self.force_dense_path = False
+        # diagnostics: True takes the window kernels wherever supported, also for small knot tables
+        self.force_window_path = False
 
     # ---- native plumbing ---------------------------------------------------------------
     @property
@@ -404,7 +406,7 @@ class STInterpMLP(nn.Module):
             tensors += list(st.head)
         w0 = tensors[0]
         st.keep = None
-        flags = N.FLAG_DENSE if force_dense else 0
+        flags = N.FLAG_DENSE if force_dense else (N.FLAG_WINDOW if self.force_window_path else 0)
         if self.spatial_basis.learnable:
             flags |= N.FLAG_LOG_BW
         if not w0.is_contiguous() and w0.t().is_contiguous():

@@ -45,6 +45,7 @@ def build_model(cfg, dropout=0.0):
         for (_, p), (k, v) in zip(m.named_parameters(), st.items()):
             assert tuple(p.shape) == v.shape, k
             p.copy_(torch.from_numpy(v.copy()))
+    m.force_window_path = True      # the small golden models exercise the window kernels too
     return m.to(dev())
 
 
@@ -694,6 +695,7 @@ def build_quantile_model(name, dropout=0.0):
         for (_, p), (k, v) in zip(m.named_parameters(), st.items()):
             assert tuple(p.shape) == v.shape, k
             p.copy_(torch.from_numpy(v.copy()))
+    m.force_window_path = True
     return m.to(dev()), cfg, lc
 
 
@@ -963,6 +965,7 @@ def build_learn_model(name):
         sb.log_bandwidths.copy_(torch.from_numpy(g["in_log_bw"]))
         for (k, p) in list(m.named_parameters())[2:]:
             p.copy_(torch.from_numpy(st[k].copy()))
+    m.force_window_path = True
     return m.to(dev()), cfg, kn, g
 
 
@@ -1141,6 +1144,7 @@ def test_learnable_window_follows_moved_knots(name, move, grow):
                 p.copy_(torch.from_numpy(st[k].copy()))
         m = m.to(d)
         m.force_dense_path = mode == "dense"
+        m.force_window_path = mode == "window"
         m.train()
         yp = m(X, coords, t)
         torch.nn.functional.mse_loss(yp, y).backward()
@@ -1189,3 +1193,19 @@ def test_scattered_learnable_knots_match_oracle(method, basis):
     assert np.abs(yp.detach().cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
     for k, p in m.named_parameters():
         assert rel_l2(p.grad.cpu().numpy(), go[k]) <= 2e-5, k
+
+
+def test_path_choice_small_tables_run_materialised():
+    """Default path choice: knot tables under 1024 knots take the materialising kernels (faster there),
+    larger compact-support grids the window kernels; STDADK_FLAG_WINDOW / FLAG_DENSE override it."""
+    from stnf.engine import TrainStep
+    small = build_model(cases.MODEL_CASES["default227"])
+    small.force_window_path = False
+    assert not TrainStep(small, max_batch=64).uses_window
+    small2 = build_model(cases.MODEL_CASES["default227"])
+    assert TrainStep(small2, max_batch=64).uses_window               # helper forces the window kernels
+    big = build_model(cases.MODEL_CASES["c2_b257"])
+    big.force_window_path = False
+    assert TrainStep(big, max_batch=64).uses_window
+    big2 = build_model(cases.MODEL_CASES["c2_b257"])
+    assert not TrainStep(big2, max_batch=64, force_dense=True).uses_window
