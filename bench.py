@@ -144,7 +144,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU mini-batch (reference YAML: 4096)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--dropout", type=float, default=0.1)
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a hipGraph (N = 1).  Off by default: on this ROCm the eager "
+                         "launch chain is ~4 %% faster at B = 4096 (0.180 vs 0.187 ms), the host stays ahead")
+    ap.add_argument("--no-graph", action="store_true", help="(kept for older command lines; eager is the default)")
     ap.add_argument("--dense", action="store_true", help="force the materialising (dense) kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the extra per-GPU batch sizes (N = 1 only)")
@@ -184,7 +187,7 @@ def main():
     batches_per_epoch = max(n_obs // B, 1)
     eng = TrainStep(model, lr=2e-2, weight_decay=5e-4, grad_clip=10.0,
                     ema_decay=1.0 - 1.0 / (10.0 * batches_per_epoch), max_batch=B,
-                    use_graph=(not args.no_graph) and world == 1, force_dense=args.dense)
+                    use_graph=args.graph and world == 1, force_dense=args.dense)
     perm = torch.randperm(n_obs, device=dev)
 
     def batch(i):
@@ -302,7 +305,7 @@ def main():
             "final_mean_loss": loss,
         }
         if args.gpus == 1 and not args.no_sweep:
-            def timed(b2, k2, model_kw=None, eng_kw=None):
+            def timed(b2, k2, model_kw=None, eng_kw=None, graph=None):
                 """obs/s of the same fused step for another batch size / objective / knot mode."""
                 torch.manual_seed(0)
                 mk = dict(p=0, k_spatial_centers=wl["k_spatial_centers"],
@@ -312,7 +315,7 @@ def main():
                 m2 = STInterpMLP(**mk).to(dev)
                 m2.train()
                 e2 = TrainStep(m2, lr=2e-2, weight_decay=5e-4, grad_clip=10.0, ema_decay=0.999, max_batch=b2,
-                               use_graph=not args.no_graph, **(eng_kw or {}))
+                               use_graph=args.graph if graph is None else graph, **(eng_kw or {}))
                 nb2 = max(n_obs // b2, 1)
                 for i in range(5):
                     e2.step_indexed(coords, t, y, perm[(i % nb2) * b2:(i % nb2) * b2 + b2])
@@ -328,6 +331,8 @@ def main():
                 return res
             # the survey's per-GPU batch sweep: same model, same step, other batch sizes
             out["batch_sweep"] = {str(b2): timed(b2, 40) for b2 in (16384, 65536) if b2 != B and b2 <= n_obs}
+            # the same step replayed from a hipGraph / launched eagerly (whichever `value` did not use)
+            out["other_launch_mode"] = dict(timed(B, 100, graph=not args.graph), hipgraph=not args.graph)
             # the "next" rows of SURVEY.md §8(f) on the same workload and batch: multi-quantile objectives
             # (N3) and learnable knots (N2, materialising path); reported beside, never as, `value`
             taus = [0.05, 0.25, 0.5, 0.75, 0.95]
@@ -351,6 +356,24 @@ def main():
                             output_dim=5),
                 dict(loss="pinball", quantile_levels=taus, non_crossing_weight=0.5, domain_penalty_weight=0.01))
             out["variants"]["ref_default_227_uniform_mse"] = timed(B, 60, dict(k_spatial_centers=[25, 81, 121]))
+            # A10: dense-grid inference (forward only, eval mode, hipGraph per 65 536-row chunk) on the
+            # resident observations, as the dense-grid prediction callers run it
+            from stnf.engine import Predictor
+            model.eval()
+            pr = Predictor(model, chunk=65536)
+            n_inf = min(n_obs, 65536) if n_obs < 2 * 65536 else n_obs // 65536 * 65536
+            ci, ti = coords[:n_inf].contiguous(), t[:n_inf].contiguous()
+            for _ in range(3):
+                pr.predict(ci, ti)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                pr.predict(ci, ti)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 20
+            out["variants"]["inference_forward_only"] = {"obs_per_s": n_inf / dt, "ms_per_call": dt * 1e3,
+                                                         "rows_per_call": n_inf, "path": "window"}
+            model.train()
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, B, args.dropout)
         print(json.dumps(out))
