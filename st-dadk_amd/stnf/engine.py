@@ -288,16 +288,21 @@ class TrainStep:
         t_all = t_all.view(-1)
         Xa = X_all if p > 0 else None
 
+        graphed = self.use_graph and not self.distributed
+        # a captured graph reads the indices from a static buffer; the eager chain takes them as they are
+        src = ib if graphed else (idx if idx.is_contiguous() else idx.contiguous())
+
         def enqueue():
             if self.uses_window and B > self.indexed_min_batch:
                 # the binning kernels read rows idx of the resident arrays in place
-                self._enqueue(Xa, coords_all, t_all, y_all, B, global_rows, idx=ib)
+                self._enqueue(Xa, coords_all, t_all, y_all, B, global_rows, idx=src)
             else:
-                N.gather_batch(coords_all, t_all, y_all, Xa, ib, cb, tb, yb, xb)
+                N.gather_batch(coords_all, t_all, y_all, Xa, src, cb, tb, yb, xb)
                 self._enqueue(xb, cb, tb, yb, B, global_rows)
 
-        ib.copy_(idx)
-        if self.use_graph and not self.distributed:
+        if graphed:
+            ib.copy_(idx)
+        if graphed:
             if not self._warm:
                 self._warm = True
                 enqueue()

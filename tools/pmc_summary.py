@@ -1,0 +1,44 @@
+"""Per-kernel HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
+separately, as MI355X_MICROARCH.md's HBM section prescribes; values are KiB per dispatch; gfx950
+under-counts wide coalesced reads by 2x, hence traffic = 2*FETCH + WRITE).
+usage: python tools/pmc_summary.py <fetch dir> <write dir> <out.md> <out.json> "<command line>" """
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"]
+        if "stdadk::" not in name:
+            continue
+        short = re.sub(r"^void ", "", name).split("(")[0].replace("stdadk::", "")
+        a = acc.setdefault(short, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return {k: (n, tot / n) for k, (n, tot) in acc.items()}
+
+
+fd, wd, out_md, out_json, cmd = sys.argv[1:6]
+F, W = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
+lines = ["# HBM traffic per launch (rocprofv3 PMC, separate FETCH_SIZE and WRITE_SIZE passes)", "",
+         f"Command: `{cmd}`", "",
+         "| kernel | launches | FETCH_SIZE KB | WRITE_SIZE KB | traffic MB (2*F+W) |", "|---|---|---|---|---|"]
+kern = {}
+for k in sorted(set(F) | set(W)):
+    n, f = F.get(k, (0, 0.0))
+    _, w = W.get(k, (0, 0.0))
+    traffic = (2 * f + w) * 1024
+    kern[re.sub(r"<.*", "", k)] = traffic
+    lines.append(f"| `{k}` | {n} | {f:.1f} | {w:.1f} | {traffic / 1e6:.1f} |")
+open(out_md, "w").write("\n".join(lines) + "\n")
+json.dump({"note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, C2 B=4096). "
+                   "traffic = 2*FETCH_SIZE (gfx950 under-counts wide coalesced reads by 2x, MI355X_MICROARCH.md "
+                   "HBM section) + WRITE_SIZE, in bytes.", "kernels": kern}, open(out_json, "w"), indent=1)
+print("\n".join(lines))
