@@ -98,6 +98,31 @@ __device__ __forceinline__ void gemm16_ni(f32x4 (*acc)[MAX_NI], const float *__r
   }
 }
 
+// The first 32-deep weight chunk of a GEMM phase, requested one phase EARLY (before the row-local
+// LayerNorm / input phase that precedes the GEMM) so that its L2 round trip is hidden behind that phase.
+static_assert(MAX_NI == 1, "the preloaded variant below assumes one N tile per wave");
+__device__ __forceinline__ void preload_w(BFrag<1> &f, const float *__restrict__ Wn, int N, int K, int wave, int c16,
+                                          int q) {
+  if (wave < (N >> 4)) load_bfrag<1>(f, Wn, K, 0, wave, c16, q);
+}
+
+// gemm16 with chunk 0 already in registers (see preload_w)
+template <int MT>
+__device__ __forceinline__ void gemm16_pre(f32x4 (*acc)[MAX_NI], const float *__restrict__ A, const float *__restrict__ Wn,
+                                           int N, int K, int wave, int c16, int q, BFrag<1> &f0) {
+  if (wave >= (N >> 4)) return;                 // scalar: this wave has no N tile in a narrow layer
+  const int nchunk = (K + 31) >> 5;
+  BFrag<1> f1;
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 1 < nchunk) load_bfrag<1>(f1, Wn, K, c + 1, wave, c16, q);
+    mma_chunk<1, MT>(acc, f0, A, K, c, c16, q);
+    if (c + 1 < nchunk) {
+      if (c + 2 < nchunk) load_bfrag<1>(f0, Wn, K, c + 2, wave, c16, q);
+      mma_chunk<1, MT>(acc, f1, A, K, c + 1, c16, q);
+    }
+  }
+}
+
 // acc[mt][i] (rows 16 mt.., N-tile t = wave + NW i) += A[R x K] (LDS, row stride ACT_LD) * Wn[N x K]^T where Wn is
 // row-major [N][K] in global memory (K contiguous).  M = 16 is the GEMV-like regime: every wave
 // streams ITS OWN slice of W straight into VGPRs (no LDS staging, no workgroup barrier in the K
@@ -131,6 +156,8 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = blockIdx.x * R;
   STAMP(0);
+  BFrag<1> wpre;
+  if (a.n_layers > 0) preload_w(wpre, a.L[0].W, a.L[0].h, a.L[0].hp, wave, c16, q);
   {
     // input tile: unconditional loads from clamped rows (rows >= B duplicate the last row; nothing
     // computed for them is ever stored), 4 per thread in flight
@@ -182,7 +209,8 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm16<MT>(acc, cur, L.W, h, hp, wave, c16, q);
+    gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre);
+    if (li + 1 < a.n_layers) preload_w(wpre, a.L[li + 1].W, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q);
     STAMP(2 + 4 * li);
     // z = acc + bias into the other activation buffer
 #pragma unroll
@@ -322,6 +350,29 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = blockIdx.x * R;
+  // Global inputs of a layer's LayerNorm-backward phase: all loads issued together from clamped
+  // addresses, unconditionally (one L2 round trip), and one phase EARLY — for the last layer right here
+  // (hidden behind the head phase),
+  // for layer li-1 just before the dA GEMM of pass li, so the round trip hides behind the MFMA work.
+  float gv[4], bev[4], xv[RPW][4], rsv[RPW];
+  auto ln_inputs = [&](const TailLayer &Ln) {
+    const int hn = Ln.h;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int colc = min(lane + 64 * cc, hn - 1);
+      gv[cc] = a.layernorm ? Ln.g[colc] : 1.f;
+      bev[cc] = a.layernorm ? Ln.be[colc] : 0.f;
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int growc = min(row0 + RPW * wave + rr, a.B - 1);
+        xv[rr][cc] = Ln.xhat[(size_t)growc * hn + colc];
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) rsv[rr] = a.layernorm ? Ln.rstd[min(row0 + RPW * wave + rr, a.B - 1)] : 1.f;
+  };
+  ln_inputs(a.L[a.n_layers - 1]);
+
   if (tid < R * TAIL_MAXQ) {
     const int row = tid / a.Q, qq = tid - row * a.Q;
     sdy[tid] = (tid < R * a.Q && row0 + row < a.B) ? a.dY[(size_t)(row0 + row) * a.Q + qq] : 0.f;
@@ -342,11 +393,18 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
       float pw[TAIL_MAXQ];
 #pragma unroll
       for (int qq = 0; qq < TAIL_MAXQ; ++qq) pw[qq] = 0.f;
-      for (int row = 0; row < nrow; ++row) {
-        const float av = a.act_last[(size_t)(row0 + row) * hl + col];
+      // 16 rows of the last activations in flight at a time (clamped rows: sdy is 0 beyond the batch)
 #pragma unroll
-        for (int qq = 0; qq < TAIL_MAXQ; ++qq)
-          if (qq < a.Q) pw[qq] = fmaf(sdy[row * a.Q + qq], av, pw[qq]);
+      for (int rb = 0; rb < R; rb += 16) {
+        float av[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          av[r] = a.act_last[(size_t)min(row0 + rb + r, a.B - 1) * hl + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int qq = 0; qq < TAIL_MAXQ; ++qq)
+            if (qq < a.Q) pw[qq] = fmaf(sdy[(rb + r) * a.Q + qq], av[r], pw[qq]);
       }
 #pragma unroll
       for (int qq = 0; qq < TAIL_MAXQ; ++qq)
@@ -366,24 +424,13 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   for (int li = a.n_layers - 1; li >= 0; --li) {
     const TailLayer &L = a.L[li];
     const int h = L.h;
-    // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows 4w .. 4w+3 of this wave.
-    // All global loads of the phase (xhat of 4 rows, gamma, beta, rstd) are issued up front from
-    // clamped addresses, unconditionally, so they share one L2 round trip.
-    float pg[4], pb[4], pz[4], gv[4], bev[4], xv[RPW][4], rsv[RPW];
+    BFrag<1> wpre;
+    if (li > 0) preload_w(wpre, a.WT[li], L.hp, h, wave, c16, q);     // for the dA GEMM at the end of this pass
+    // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows RPW*w .. of this wave.  Its global inputs
+    // (xhat rows, gamma, beta, rstd) were requested one phase early (ln_inputs below).
+    float pg[4], pb[4], pz[4];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      pg[cc] = pb[cc] = pz[cc] = 0.f;
-      const int colc = min(lane + 64 * cc, h - 1);
-      gv[cc] = a.layernorm ? L.g[colc] : 1.f;
-      bev[cc] = a.layernorm ? L.be[colc] : 0.f;
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int growc = min(row0 + RPW * wave + rr, a.B - 1);
-        xv[rr][cc] = L.xhat[(size_t)growc * h + colc];
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) rsv[rr] = a.layernorm ? L.rstd[min(row0 + RPW * wave + rr, a.B - 1)] : 1.f;
+    for (int cc = 0; cc < 4; ++cc) pg[cc] = pb[cc] = pz[cc] = 0.f;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = RPW * wave + rr;
@@ -456,8 +503,9 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ln_inputs(a.L[li - 1]);        // consumed after the GEMM, in the next pass
     lds_barrier();                 // every wave's dZ rows are in `cur`
-    gemm16<MT>(acc, cur, a.WT[li], hp, h, wave, c16, q);
+    gemm16_pre<MT>(acc, cur, a.WT[li], hp, h, wave, c16, q, wpre);
 #pragma unroll
     for (int i = 0; i < MAX_NI; ++i) {
       const int t = wave + NW * i;
