@@ -695,10 +695,35 @@ __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
     }
   };
 
-  for (int cx = cx_lo; cx <= cx_hi; ++cx) {
-    const int s0 = a.cell_start[cx * G + cy_lo], s1 = a.cell_start[cx * G + cy_hi + 1];
-    for (int base = s0; base < s1; base += 64) {
-      const int i = base + lane;
+  // The sorted-observation segments of up to 64 cell columns are fetched by 64 lanes at once and
+  // walked as ONE flat candidate list (same order as column by column), so a knot's ~40 candidates
+  // cost two dependent memory round trips instead of two per column.
+  for (int cxb = cx_lo; cxb <= cx_hi; cxb += 64) {
+    const int cxl = cxb + lane;
+    int seg0 = 0, seg1 = 0;
+    if (cxl <= cx_hi) { seg0 = a.cell_start[cxl * G + cy_lo]; seg1 = a.cell_start[cxl * G + cy_hi + 1]; }
+    int incl = seg1 - seg0;                       // inclusive prefix of the segment lengths
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    const int total = __shfl(incl, 63, 64);
+    for (int f0 = 0; f0 < total; f0 += 64) {
+      const int f = f0 + lane;
+      // segment j with incl[j-1] <= f < incl[j]: first lane whose inclusive prefix exceeds f
+      int lo = 0;
+#pragma unroll
+      for (int st = 32; st > 0; st >>= 1) {
+        const int probe = __shfl(incl, lo + st - 1, 64);
+        if (probe <= f) lo += st;
+      }
+      const int jl = lo < 63 ? lo : 63;
+      const int pin = __shfl(incl, jl, 64);
+      const int pl = __shfl(seg1 - seg0, jl, 64);
+      const int ps0 = __shfl(seg0, jl, 64);
+      const int i = ps0 + (f - (pin - pl));
+      const int s1 = f < total ? i + 1 : i;       // keeps the `i < s1` form of the validity test below
       float phi = 0.f;
       float q0 = 0.f, q1 = 0.f, q2 = 0.f;
       if (i < s1) {
