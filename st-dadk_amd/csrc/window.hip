@@ -388,15 +388,15 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
     auto consume = [&](int cnt) {
       for (int e0 = 0; e0 < cnt; e0 += 8) {
         float pv[8];
-        const float *rp[8];
+        unsigned ro[8];              // 32-bit element offsets: scalar base + vector offset addressing
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           pv[e] = my_phi[e0 + e];
-          rp[e] = a.W0T + (size_t)my_k[e0 + e] * H + CPL * lane;
+          ro[e] = (unsigned)my_k[e0 + e] * (unsigned)H + (unsigned)(CPL * lane);
         }
         typename VecT<CPL>::T wv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(rp[e]);
+        for (int e = 0; e < 8; ++e) wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(a.W0T + (size_t)ro[e]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float *f = reinterpret_cast<const float *>(&wv[e]);
@@ -412,9 +412,9 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
     for (int l0 = 0; l0 < a.g.n_levels; l0 += LSTEP) {
       int n = 0;
       const int l1 = min(l0 + LSTEP, a.g.n_levels);
-      for (int l = l0; l < l1; ++l) {
+      for (int l = l0; FREE && l < l1; ++l) {
         const int side = a.g.side[l];
-        if (FREE) {
+        {
           const int R = a.halo[l];
           const int win = min(2 * R, side);
           const int hi = side - win;
@@ -448,25 +448,43 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
             }
             n += m;
           }
-          continue;
         }
-        const int win = side < WIN ? side : WIN;
-        const int ix0 = window_start(x, side, win), iy0 = window_start(y, side, win);
-        const int dx = lane / WIN, dy = lane - dx * WIN;
-        float phi = 0.f;
-        int k = 0;
-        if (lane < WIN * WIN && dx < win && dy < win) {
-          k = a.g.off[l] + (ix0 + dx) * side + iy0 + dy;
-          phi = phi_eval<BASIS>(x, y, a.g.centers[2 * k], a.g.centers[2 * k + 1],
-                                knot_scale(a.g.bw[k], a.g.cal));
+      }
+      if (!FREE) {
+        // knot table entries of all (up to three) levels of the chunk requested together, from clamped
+        // indices and unconditionally, so they share one round trip; evaluated level by level after
+        int kk[3];
+        bool ok[3];
+        float kx[3], ky[3], kb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          kk[j] = 0; ok[j] = false;
+          if (l0 + j < l1) {                      // wave-uniform
+            const int l = l0 + j;
+            const int side = a.g.side[l];
+            const int win = side < WIN ? side : WIN;
+            const int ix0 = window_start(x, side, win), iy0 = window_start(y, side, win);
+            const int dx = lane / WIN, dy = lane - dx * WIN;
+            ok[j] = lane < WIN * WIN && dx < win && dy < win;
+            kk[j] = a.g.off[l] + (ok[j] ? (ix0 + dx) * side + iy0 + dy : 0);
+          }
+          kx[j] = a.g.centers[2 * kk[j]];
+          ky[j] = a.g.centers[2 * kk[j] + 1];
+          kb[j] = a.g.bw[kk[j]];
         }
-        const uint64_t mask = __ballot(phi != 0.f);
-        if (phi != 0.f) {
-          const int pos = n + __popcll(mask & below);
-          my_phi[pos] = phi;
-          my_k[pos] = a.g.p + k;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (l0 + j < l1) {
+            const float phi = ok[j] ? phi_eval<BASIS>(x, y, kx[j], ky[j], knot_scale(kb[j], a.g.cal)) : 0.f;
+            const uint64_t mask = __ballot(phi != 0.f);
+            if (phi != 0.f) {
+              const int pos = n + __popcll(mask & below);
+              my_phi[pos] = phi;
+              my_k[pos] = a.g.p + kk[j];
+            }
+            n += __popcll(mask);
+          }
         }
-        n += __popcll(mask);
       }
       if (l0 == 0 && a.g.p > 0) {            // covariate columns [0, p): dense
         if (lane < a.g.p) {
@@ -594,6 +612,8 @@ static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
 
 int l1_window_forward(const L1FwdArgs &a_in, int basis, bool ln, hipStream_t st) {
   L1FwdArgs a = a_in;
+  STDADK_REQUIRE((int64_t)(a.g.p + a.g.Ks + a.g.Kt) * a.H < (1ll << 32), STDADK_E_ARG,
+                 "l1_window_forward: D*H exceeds 32-bit offsets");
   // one 16-wave workgroup per CU (~95 KiB LDS), multiple of 8 for the XCD mapping
   int n_wg = 256;
   while (n_wg > 8 && (int64_t)(n_wg / 2) * (FW_T / 64) >= a.B) n_wg >>= 1;
@@ -676,7 +696,8 @@ __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         pv[e] = my_phi[e0 + e];
-        wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(a.dZ + (size_t)my_idx[e0 + e] * H + CPL * lane);
+        wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(
+            a.dZ + (size_t)((unsigned)my_idx[e0 + e] * (unsigned)H + (unsigned)(CPL * lane)));
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -799,6 +820,7 @@ __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
 
 int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st) {
   STDADK_REQUIRE(a.G <= 256, STDADK_E_ARG, "l1_window_backward: G too large");
+  STDADK_REQUIRE((int64_t)a.B * a.H < (1ll << 32), STDADK_E_ARG, "l1_window_backward: B*H exceeds 32-bit offsets");
   const unsigned grid = (unsigned)ceil_div(a.g.Ks, BW_T / 64);
   STDADK_REQUIRE(!a.kpart || a.W0T, STDADK_E_ARG, "l1_window_backward: knot sums need W0^T");
 #define GO(CPL_, BS_)                                                                                        \
