@@ -217,6 +217,9 @@ typedef struct stdadk_basis_desc {
 
 #define STDADK_FLAG_DENSE 1 /* force the materialising path                                    */
 #define STDADK_FLAG_W0_T 2  /* params->W[0] and grads->W[0] are (in,out) row-major              */
+#define STDADK_FLAG_PREBINNED 16 /* window path: the batch was already binned into this workspace by
+                              * stdadk_bin_batch_f32 (e.g. on another stream while the previous step
+                              * ran); the step entry points skip the binning and ignore coords/t/X/y */
 #define STDADK_FLAG_WINDOW 8 /* take the window path whenever it is supported, even for small knot
                               * tables (default: tables under 1024 knots run the materialising
                               * path, which is faster there: a coarse level's few knots each own a
@@ -316,6 +319,17 @@ int stdadk_train_fwd_bwd_indexed_f32(const stdadk_basis_desc *basis, const stdad
                                      void *workspace, size_t workspace_bytes, uint64_t drop_seed,
                                      const int32_t *step_dev, int32_t flags, stdadk_stream_t stream,
                                      stdadk_stream_t aux_stream);
+
+/* A0, window path: the batch-preparation half of the step on its own — gathers rows idx[b] (NULL = rows
+ * 0..B-1) of coords_all / t_all / X_all / y_all [N, y_cols] and bins them into `workspace`, exactly as
+ * the step entry points would.  Software pipelining: call it for batch k+1 on a second stream (and a
+ * second workspace) while step k runs, then run step k+1 with STDADK_FLAG_PREBINNED.  The caller
+ * orders the streams (the workspace must not be in use by an unfinished step). */
+int stdadk_bin_batch_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                         const float *coords_all, const float *t_all, const float *X_all,
+                         const float *y_all, const int64_t *idx, int64_t B, int32_t y_cols,
+                         void *workspace, size_t workspace_bytes, int32_t flags,
+                         stdadk_stream_t stream);
 
 /* A0  batch producer (scripts/train_st_interp.py:413-460 dataset + collate, :609-612 H2D): rows
  * idx[b] (int64) of the device-resident observation arrays into contiguous batch buffers, one launch.

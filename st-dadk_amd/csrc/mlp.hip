@@ -483,6 +483,7 @@ struct Ctx {
   bool mse_done = false;        // set by run_forward when the loss was fused into the tail kernel
   bool log_bw = false;          // basis->s_bw holds log-bandwidths (learnable knots)
   const int64_t *idx = nullptr; // window path: the batch is rows idx[b] of the resident observation arrays
+  bool prebinned = false;       // window path: stdadk_bin_batch_f32 already filled the workspace's bins
   LossDev loss = {STDADK_LOSS_MSE, 0, {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f}, 0.f, 1};   // y_cols 0 = Q
   const float *dz0 = nullptr;   // set by run_backward: dZ of layer 0
   // optional second stream: independent kernels of a step fork onto it (hipGraph-capturable
@@ -879,9 +880,13 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
                                  const float *X, const float *y) {
   const Plan &pl = c.pl;
   BinBuffers bb = plan_bins(c.ws, pl);
-  int rc = bin_obs(coords, t, y, c.loss.y_cols ? c.loss.y_cols : c.d->out_dim, X, b->p, (int)c.B, pl.G, bb, c.st,
-                   c.idx);
-  if (rc) return rc;
+  int rc = 0;
+  if (!c.prebinned) {
+    STDADK_REQUIRE(coords && t && (b->p == 0 || X), STDADK_E_ARG, "step: NULL observation pointer");
+    rc = bin_obs(coords, t, y, c.loss.y_cols ? c.loss.y_cols : c.d->out_dim, X, b->p, (int)c.B, pl.G, bb, c.st,
+                 c.idx);
+    if (rc) return rc;
+  }
   L1FwdArgs a;
   a.g = make_grid(b);
   a.halo = nullptr;
@@ -1002,6 +1007,9 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
   c.d = d; c.ws = (float *)workspace; c.B = B;
   c.w0t = (flags & STDADK_FLAG_W0_T) != 0;
   c.masks = nullptr;
+  c.prebinned = *window && (flags & STDADK_FLAG_PREBINNED) != 0;
+  STDADK_REQUIRE(*window || !(flags & STDADK_FLAG_PREBINNED), STDADK_E_ARG,
+                 "step: STDADK_FLAG_PREBINNED needs the window path");
   return 0;
 }
 
@@ -1209,9 +1217,9 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
                  "train_fwd_bwd_indexed: only the window path gathers in place; use stdadk_gather_batch_f32 + "
                  "stdadk_train_fwd_bwd_f32 for the materialising path");
   c.idx = idx;
-  STDADK_REQUIRE(P && G && coords && t && y, STDADK_E_ARG, "train_fwd_bwd: NULL pointer");
+  STDADK_REQUIRE(P && G && (c.prebinned || (coords && t && y)), STDADK_E_ARG, "train_fwd_bwd: NULL pointer");
   c.aux = (aux_stream && aux_stream != stream) ? (hipStream_t)aux_stream : nullptr;
-  STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "train_fwd_bwd: X is NULL with p=%d", b->p);
+  STDADK_REQUIRE(b->p == 0 || X || c.prebinned, STDADK_E_ARG, "train_fwd_bwd: X is NULL with p=%d", b->p);
   c.P = P; c.G = G; c.st = (hipStream_t)stream; c.dp = d->dropout_p; c.seed = drop_seed; c.step_dev = step_dev;
   rc = make_loss(loss, d->out_dim, &c.loss);
   if (rc) return rc;
@@ -1254,6 +1262,28 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
     if (rc) return rc;
   }
   return step_backward(c, b, false, c.ws + c.pl.dY, false);
+}
+
+extern "C" int stdadk_bin_batch_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                    const float *coords_all, const float *t_all, const float *X_all,
+                                    const float *y_all, const int64_t *idx, int64_t B, int32_t y_cols,
+                                    void *workspace, size_t workspace_bytes, int32_t flags,
+                                    stdadk_stream_t stream) {
+  if (B == 0) return 0;
+  Ctx c;
+  bool window;
+  int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags & ~STDADK_FLAG_PREBINNED, &window);
+  if (rc) return rc;
+  STDADK_REQUIRE(window, STDADK_E_ARG, "bin_batch: only the window path bins its batches");
+  STDADK_REQUIRE(coords_all && t_all && (b->p == 0 || X_all), STDADK_E_ARG, "bin_batch: NULL pointer");
+  STDADK_REQUIRE(y_cols >= 0 && y_cols <= d->out_dim && (y_cols == 0 || y_all), STDADK_E_ARG,
+                 "bin_batch: y_cols=%d must be in 0..Q with y_all given", y_cols);
+  BinBuffers bb = plan_bins(c.ws, c.pl);
+  // beside a running step the binning goes as several launches of small workgroups, which share CUs
+  // with the step's one-workgroup-per-CU kernels; a single 1024-thread workgroup would take a whole CU
+  // away from them for its entire duration
+  return bin_obs(coords_all, t_all, y_cols > 0 ? y_all : nullptr, y_cols, X_all, b->p, (int)B, c.pl.G, bb,
+                 (hipStream_t)stream, idx, getenv("STDADK_BIN_BATCH_SMALL") == nullptr);
 }
 
 extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,

@@ -40,7 +40,8 @@ int pick_cell_grid(int64_t B);   // G: cells per axis, power of two in [8, 256]
 
 // idx (optional): the batch is rows idx[b] of resident arrays coords/t/y/X; perm holds batch positions
 int bin_obs(const float *coords, const float *t, const float *y, int Q, const float *X, int p,
-            int B, int G, const BinBuffers &bb, hipStream_t st, const int64_t *idx = nullptr);
+            int B, int G, const BinBuffers &bb, hipStream_t st, const int64_t *idx = nullptr,
+            bool many_small = false);   // many_small: never the one-workgroup kernel (see stdadk_bin_batch_f32)
 
 struct L1FwdArgs {
   GridView g;

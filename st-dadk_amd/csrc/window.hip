@@ -259,9 +259,9 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const int64_t *__restri
 }
 
 int bin_obs(const float *coords, const float *t, const float *y, int Q, const float *X, int p, int B,
-            int G, const BinBuffers &bb, hipStream_t st, const int64_t *idx) {
+            int G, const BinBuffers &bb, hipStream_t st, const int64_t *idx, bool many_small) {
   const int ncell = G * G;
-  if (B <= SMALL_B && G <= SMALL_G) {
+  if (B <= SMALL_B && G <= SMALL_G && !many_small) {
     STDADK_LAUNCH(bin_small_kernel, dim3(1), dim3(1024), 0, st, idx, coords, t, y, Q, X, p, B, G, bb.keys,
                   bb.cell_start, bb.perm, bb.xs, bb.ys, bb.ts, y ? bb.y_s : (float *)nullptr,
                   (X && p > 0) ? bb.X_s : (float *)nullptr);

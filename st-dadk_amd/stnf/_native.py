@@ -58,6 +58,7 @@ FLAG_DENSE = 1
 FLAG_W0_T = 2
 FLAG_LOG_BW = 4
 FLAG_WINDOW = 8
+FLAG_PREBINNED = 16
 
 _lib = None
 
@@ -111,6 +112,9 @@ _SIGNATURES = {
                                                    C.c_float, C.POINTER(LossDesc), C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_int32,
                                                    C.c_void_p, C.c_void_p]),
+    "stdadk_bin_batch_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                       C.c_size_t, C.c_int32, C.c_void_p]),
     "stdadk_gather_batch_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -413,6 +417,18 @@ def train_fwd_bwd_indexed(basis, desc, params, grads, coords_all, t_all, X_all, 
         _dev(step_dev, "step_dev"), flags, _stream(),
         aux_stream.cuda_stream if aux_stream is not None else None)
     _check(rc, "stdadk_train_fwd_bwd_indexed_f32")
+
+
+def bin_batch(basis, desc, coords_all, t_all, X_all, y_all, idx, workspace, flags):
+    """Batch preparation of the window path on its own (rows `idx` of the resident arrays binned into
+    `workspace`) on the current stream; the step then runs with FLAG_PREBINNED."""
+    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+        raise RuntimeError("bin_batch: idx must be a contiguous int64 tensor on the device")
+    rc = lib().stdadk_bin_batch_f32(C.byref(basis), C.byref(desc), _dev(coords_all, "coords"), _dev(t_all, "t"),
+                                    _dev(X_all, "X"), _dev(y_all, "y"), idx.data_ptr(), idx.numel(),
+                                    y_all.shape[1] if y_all is not None else 0, workspace.data_ptr(),
+                                    workspace.numel() * workspace.element_size(), flags, _stream())
+    _check(rc, "stdadk_bin_batch_f32")
 
 
 def make_knot_train(centers_init, gradient_damping=False, damping_threshold=0.3, damping_strength=1.0,

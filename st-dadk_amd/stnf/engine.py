@@ -168,6 +168,8 @@ class TrainStep:
         self._warm = False
         self._ix = None
         self._ix_graph = None
+        self._pipe = None          # two workspaces + side stream of the pipelined batch preparation
+        self._prepared = None      # ((idx data_ptr, numel), workspace index, idx tensor) of the announced batch
 
     # ------------------------------------------------------------------------------------
     def set_lr(self, lr):
@@ -182,22 +184,25 @@ class TrainStep:
         self.basis_lr = float(lr)
         self.basis_lr_dev.fill_(self.basis_lr)
 
-    def _enqueue(self, X, coords, t, y, B, global_rows, idx=None):
+    def _enqueue(self, X, coords, t, y, B, global_rows, idx=None, ws=None, prebinned=False):
         """All kernels of one step on the current stream (capturable: no sync, no allocation).
-        With `idx` (window path) X/coords/t/y are the RESIDENT arrays and the batch is their rows idx."""
+        With `idx` (window path) X/coords/t/y are the RESIDENT arrays and the batch is their rows idx;
+        `prebinned`: the batch already sits binned in workspace `ws` (pipelined preparation)."""
         st = self.state
+        ws = self.ws if ws is None else ws
+        flags = st.flags | (N.FLAG_PREBINNED if prebinned else 0)
         Q = self.model.output_dim
         if st.head is not None:
             N.delta_head(st.delta, st.head[0], st.head[1])          # output layer of this step's delta
         # d(mean over the GLOBAL batch)/dparams: each rank scales by 1/global_rows, the all-reduce SUMs
-        if idx is not None:
+        if idx is not None and not prebinned:
             N.train_fwd_bwd_indexed(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, idx,
-                                    D.grad_scale(global_rows, Q), self.loss_sum, None, self.ws, st.flags,
+                                    D.grad_scale(global_rows, Q), self.loss_sum, None, ws, flags,
                                     seed=self.seed, step_dev=self.step_dev, aux_stream=self.aux_stream,
                                     loss_desc=self._loss_desc(y.shape[1]))
         else:
             N.train_fwd_bwd(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, B,
-                            D.grad_scale(global_rows, Q), self.loss_sum, None, self.ws, st.flags,
+                            D.grad_scale(global_rows, Q), self.loss_sum, None, ws, flags,
                             seed=self.seed, step_dev=self.step_dev, aux_stream=self.aux_stream,
                             loss_desc=self._loss_desc(y.shape[1]))
         if st.head is not None:
@@ -211,7 +216,7 @@ class TrainStep:
             kt = N.make_knot_train(sb.centers_init, sb.gradient_damping, sb.damping_threshold,
                                    sb.damping_strength, self.domain_w, self.movement_w,
                                    penalty_grad_scale=1.0 / self.world, penalty_loss_scale=float(B * Q))
-            N.knot_backward(st.basis, st.desc, st.params, coords, B, self.ws, st.flags, kt,
+            N.knot_backward(st.basis, st.desc, st.params, coords, B, ws, st.flags, kt,
                             self.g_centers, self.g_log_bw, self.loss_sum)
         if self.distributed:
             D.allreduce_gradients(self.grad, self.pg)
@@ -266,12 +271,17 @@ class TrainStep:
         self.step_count += 1
         self.rows_seen += B
 
-    def step_indexed(self, coords_all, t_all, y_all, idx, X_all=None, global_rows=None):
+    def step_indexed(self, coords_all, t_all, y_all, idx, X_all=None, global_rows=None, next_idx=None):
         """One optimisation step on rows `idx` (int64 device tensor) of device-RESIDENT observation
         arrays coords_all (N,2), t_all (N,) or (N,1), y_all (N,Q), X_all (N,p)|None.  The batch is
         gathered by one library kernel into static buffers (the reference builds it from a Python
         list of dicts, torch.stack and four H2D copies per step: train_st_interp.py:413-460,609-612);
-        with use_graph the gather is part of the captured graph."""
+        with use_graph the gather is part of the captured graph.
+
+        `next_idx` (window path, eager launch chain): the rows of the FOLLOWING step.  Their gather and
+        binning are enqueued on a second stream into a second workspace while this step runs, and the
+        following call (same tensor as its `idx`) starts at the layer-0 kernel — batch preparation
+        leaves the critical path.  The index tensors must not be modified in between."""
         B = idx.numel()
         if B > self.max_batch:
             raise RuntimeError(f"batch {B} > max_batch {self.max_batch}")
@@ -291,6 +301,11 @@ class TrainStep:
         graphed = self.use_graph and not self.distributed
         # a captured graph reads the indices from a static buffer; the eager chain takes them as they are
         src = ib if graphed else (idx if idx.is_contiguous() else idx.contiguous())
+        if self.uses_window and not graphed and (next_idx is not None or self._prepared is not None):
+            self._step_pipelined(coords_all, t_all, y_all, Xa, src, next_idx, B, global_rows)
+            self.step_count += 1
+            self.rows_seen += B
+            return
 
         def enqueue():
             if self.uses_window and B > self.indexed_min_batch:
@@ -319,6 +334,37 @@ class TrainStep:
             enqueue()
         self.step_count += 1
         self.rows_seen += B
+
+    def _step_pipelined(self, coords_all, t_all, y_all, Xa, idx, next_idx, B, global_rows):
+        """Step on a batch that was (or is now) binned into one of two workspaces, and batch
+        preparation of `next_idx` on the side stream into the other one."""
+        main = torch.cuda.current_stream(self.dev)
+        if self._pipe is None:
+            self._pipe = dict(ws=[self.ws, torch.empty_like(self.ws)], stream=torch.cuda.Stream(device=self.dev),
+                              done=[torch.cuda.Event(), torch.cuda.Event()], binned=torch.cuda.Event(), last=1)
+        pp = self._pipe
+        st = self.state
+        prep = self._prepared
+        self._prepared = None
+        if prep is not None and prep[0] == (idx.data_ptr(), idx.numel()):
+            wsi, prebinned = prep[1], True
+            main.wait_event(pp["binned"])
+        else:
+            wsi, prebinned = 1 - pp["last"], False        # not announced: bin inside the step, in place
+        if next_idx is not None:
+            nxt = next_idx if next_idx.is_contiguous() else next_idx.contiguous()
+            wsj = 1 - wsi
+            pp["stream"].wait_event(pp["done"][wsj])       # the last step that used that workspace is over
+            with torch.cuda.stream(pp["stream"]):
+                N.bin_batch(st.basis, st.desc, coords_all, t_all, Xa, y_all, nxt, pp["ws"][wsj], st.flags)
+                pp["binned"].record(pp["stream"])
+            self._prepared = ((nxt.data_ptr(), nxt.numel()), wsj, nxt)
+        if prebinned:
+            self._enqueue(None, None, None, y_all, B, global_rows, ws=pp["ws"][wsi], prebinned=True)
+        else:
+            self._enqueue(Xa, coords_all, t_all, y_all, B, global_rows, idx=idx, ws=pp["ws"][wsi])
+        pp["done"][wsi].record(main)
+        pp["last"] = wsi
 
     def _step_graph(self, X, coords, t, y, B, global_rows):
         if not self._warm:

@@ -1209,3 +1209,44 @@ def test_path_choice_small_tables_run_materialised():
     assert TrainStep(big, max_batch=64).uses_window
     big2 = build_model(cases.MODEL_CASES["c2_b257"])
     assert not TrainStep(big2, max_batch=64, force_dense=True).uses_window
+
+
+@pytest.mark.parametrize("name", ["default227", "default227_learn", "default227_mq5"])
+def test_pipelined_batch_preparation_equals_inline(name):
+    """next_idx: gather + binning of the following batch on a side stream into a second workspace;
+    the parameters after several steps are bit-identical with the in-step preparation (same binning,
+    same arithmetic), also when an announced batch is not the one that follows."""
+    from stnf.engine import TrainStep
+    d = dev()
+    rs = np.random.RandomState(5)
+    n = 3000
+    coords = torch.from_numpy(rs.uniform(0, 1, (n, 2)).astype(np.float32)).to(d)
+    t = torch.from_numpy(rs.uniform(0, 1, (n,)).astype(np.float32)).to(d)
+    y = torch.from_numpy(rs.standard_normal((n, 1)).astype(np.float32)).to(d)
+    perm = torch.from_numpy(rs.permutation(n).astype(np.int64)).to(d)
+    res = []
+    for mode in ("inline", "pipelined", "pipelined_mispredicted"):
+        kw = {}
+        if name in cases.LEARN_CASES:
+            m, cfg, kn, g = build_learn_model(name)
+            kw = dict(domain_penalty_weight=0.01)
+        elif name in cases.QUANTILE_CASES:
+            m, cfg, lc = build_quantile_model(name)
+            kw = dict(loss="pinball", quantile_levels=lc["taus"], non_crossing_weight=0.5)
+        else:
+            m = build_model(cases.MODEL_CASES[name])
+        m.train()
+        eng = TrainStep(m, lr=1e-3, ema_decay=0.99, max_batch=256, **kw)
+        assert eng.uses_window
+        for s in range(6):
+            idx = perm[256 * s:256 * s + 256]
+            nxt = perm[256 * (s + 1):256 * (s + 1) + 256]
+            if mode == "inline":
+                eng.step_indexed(coords, t, y, idx)
+            elif mode == "pipelined":
+                eng.step_indexed(coords, t, y, idx, next_idx=nxt)
+            else:       # announces a batch that is NOT used next every other step
+                eng.step_indexed(coords, t, y, idx, next_idx=nxt if s % 2 else perm[:256])
+        res.append((eng.flat.clone(), eng.mean_loss()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][0], res[2][0])
+    assert abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[0][1])
