@@ -54,6 +54,40 @@ def flatten_parameters(model, transpose_first=True):
     return flat, offs
 
 
+def _wait(stream, ev):
+    if isinstance(ev, _LightEvent):
+        import ctypes
+        if ev.recorded:
+            rc = _LightEvent._hip.hipStreamWaitEvent(ctypes.c_void_p(stream.cuda_stream), ev.h, 0)
+            if rc:
+                raise RuntimeError(f"hipStreamWaitEvent failed: {rc}")
+    else:
+        stream.wait_event(ev)
+
+
+class _LightEvent:
+    """HIP event without timing and without the system-scope fence (hipEventDisableSystemFence): the
+    streams it orders are on one device."""
+    _hip = None
+
+    def __init__(self):
+        import ctypes
+        if _LightEvent._hip is None:
+            _LightEvent._hip = ctypes.CDLL("libamdhip64.so")
+        self.h = ctypes.c_void_p()
+        rc = _LightEvent._hip.hipEventCreateWithFlags(ctypes.byref(self.h), 0x2 | 0x20000000)
+        if rc:
+            raise RuntimeError(f"hipEventCreateWithFlags failed: {rc}")
+        self.recorded = False
+
+    def record(self, stream):
+        import ctypes
+        rc = _LightEvent._hip.hipEventRecord(self.h, ctypes.c_void_p(stream.cuda_stream))
+        if rc:
+            raise RuntimeError(f"hipEventRecord failed: {rc}")
+        self.recorded = True
+
+
 class TrainStep:
     """One fused optimisation step of STInterpMLP (fixed knots).
 
@@ -340,21 +374,28 @@ class TrainStep:
         preparation of `next_idx` on the side stream into the other one."""
         main = torch.cuda.current_stream(self.dev)
         if self._pipe is None:
+            # events without the system-scope fence (both streams are on this device): 3 us per step
+            # cheaper than torch.cuda.Event on MI355X; fall back if the HIP runtime cannot be reached
+            try:
+                _LightEvent()
+                mk = _LightEvent
+            except (OSError, RuntimeError, AttributeError):
+                mk = torch.cuda.Event
             self._pipe = dict(ws=[self.ws, torch.empty_like(self.ws)], stream=torch.cuda.Stream(device=self.dev),
-                              done=[torch.cuda.Event(), torch.cuda.Event()], binned=torch.cuda.Event(), last=1)
+                              done=[mk(), mk()], binned=mk(), last=1)
         pp = self._pipe
         st = self.state
         prep = self._prepared
         self._prepared = None
         if prep is not None and prep[0] == (idx.data_ptr(), idx.numel()):
             wsi, prebinned = prep[1], True
-            main.wait_event(pp["binned"])
+            _wait(main, pp["binned"])
         else:
             wsi, prebinned = 1 - pp["last"], False        # not announced: bin inside the step, in place
         if next_idx is not None:
             nxt = next_idx if next_idx.is_contiguous() else next_idx.contiguous()
             wsj = 1 - wsi
-            pp["stream"].wait_event(pp["done"][wsj])       # the last step that used that workspace is over
+            _wait(pp["stream"], pp["done"][wsj])           # the last step that used that workspace is over
             with torch.cuda.stream(pp["stream"]):
                 N.bin_batch(st.basis, st.desc, coords_all, t_all, Xa, y_all, nxt, pp["ws"][wsj], st.flags)
                 pp["binned"].record(pp["stream"])
