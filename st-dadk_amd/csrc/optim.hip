@@ -55,6 +55,25 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
+  // The first (for up to 4 M parameters: the only) float4 group of every stream is requested BEFORE the
+  // prologue below (partials of the clip norm, bias corrections), whose latency then hides behind it.
+  typedef float nt4 __attribute__((ext_vector_type(4)));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool al = ((reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(a.g) |
+                    reinterpret_cast<uintptr_t>(a.m) | reinterpret_cast<uintptr_t>(a.v) |
+                    reinterpret_cast<uintptr_t>(a.ema)) & 15) == 0;
+  const int64_t n4 = al ? a.n / 4 : 0;
+  const int64_t jc = i0 < n4 ? i0 : (n4 > 0 ? n4 - 1 : 0);      // clamped: unconditional loads
+  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), g0 = p0;
+  nt4 m0 = {0, 0, 0, 0}, v0 = m0, e0 = m0;
+  if (n4 > 0) {
+    p0 = reinterpret_cast<float4 *>(a.p)[jc];
+    g0 = reinterpret_cast<const float4 *>(a.g)[jc];
+    m0 = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.m) + jc);
+    v0 = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.v) + jc);
+    if (a.ema) e0 = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.ema) + jc);
+  }
   const float lr = a.lr_dev ? a.lr_dev[0] : a.lr;
   const int step = a.step_dev ? a.step_dev[0] : a.step;
   float coef = 1.f;
@@ -75,23 +94,20 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   const float step_size = lr / bc1;
   const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   const float decay_mul = 1.f - lr * a.wd;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool al = ((reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(a.g) |
-                    reinterpret_cast<uintptr_t>(a.m) | reinterpret_cast<uintptr_t>(a.v) |
-                    reinterpret_cast<uintptr_t>(a.ema)) & 15) == 0;
   int64_t done = 0;
   if (al) {
-    const int64_t n4 = a.n / 4;
     // m, v and the EMA shadow are pure streams (touched once per step): non-temporal accesses keep
     // them from evicting the parameters and activations the next step wants in L2 / Infinity Cache
-    typedef float nt4 __attribute__((ext_vector_type(4)));
     for (int64_t j = i0; j < n4; j += stride) {
-      float4 p = reinterpret_cast<float4 *>(a.p)[j];
-      float4 g = reinterpret_cast<const float4 *>(a.g)[j];
-      nt4 mt = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.m) + j);
-      nt4 vt = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.v) + j);
-      nt4 et = a.ema ? __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.ema) + j) : (nt4){0, 0, 0, 0};
+      float4 p = p0, g = g0;
+      nt4 mt = m0, vt = v0, et = e0;
+      if (j != i0) {
+        p = reinterpret_cast<float4 *>(a.p)[j];
+        g = reinterpret_cast<const float4 *>(a.g)[j];
+        mt = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.m) + j);
+        vt = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.v) + j);
+        et = a.ema ? __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.ema) + j) : (nt4){0, 0, 0, 0};
+      }
       float4 m = make_float4(mt.x, mt.y, mt.z, mt.w), v = make_float4(vt.x, vt.y, vt.z, vt.w);
       float4 e = make_float4(et.x, et.y, et.z, et.w);
       float *ep = a.ema ? &e.x : nullptr;
