@@ -350,6 +350,23 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
   const int Kt_pad = (Kt + 3) & ~3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D0 = a.g.p + a.g.Ks;                      // first temporal row of W0^T
+  // XCD-aware chunking: workgroups w and w+8 share an XCD (round-robin dispatch), so XCD x walks
+  // the x-th contiguous eighth of the sorted observations and its L2 holds that eighth's W0^T rows.
+  const int w = blockIdx.x, per_x = a.n_wg >> 3;
+  const int chunk = (w & 7) * per_x + (w >> 3);
+  const int r0 = chunk * a.rows_per_wg;
+  const int r1 = min(r0 + a.rows_per_wg, a.B);
+  // the wave's first observation and the per-column parameters are requested before the temporal rows
+  // are staged, so that all of it shares one memory round trip ahead of the workgroup barrier
+  const int rowf = min(r0 + wave, a.B - 1);
+  const float xf = a.xs[rowf], yf = a.ys[rowf], tf = a.ts[rowf];
+  float bias[CPL], gam[CPL], bet[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    bias[c] = a.b0[CPL * lane + c];
+    gam[c] = LN ? a.gamma[CPL * lane + c] : 1.f;
+    bet[c] = LN ? a.beta[CPL * lane + c] : 0.f;
+  }
   {
     const float4 *src = reinterpret_cast<const float4 *>(a.W0T + (size_t)D0 * H);
     float4 *dst = reinterpret_cast<float4 *>(Wt);
@@ -359,27 +376,13 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
   float *my_phi = lphi + wave * LIST;
   int *my_k = lk + wave * LIST;
   float *my_psi = lpsi + wave * Kt_pad;
-
-  // XCD-aware chunking: workgroups w and w+8 share an XCD (round-robin dispatch), so XCD x walks
-  // the x-th contiguous eighth of the sorted observations and its L2 holds that eighth's W0^T rows.
-  const int w = blockIdx.x, per_x = a.n_wg >> 3;
-  const int chunk = (w & 7) * per_x + (w >> 3);
-  const int r0 = chunk * a.rows_per_wg;
-  const int r1 = min(r0 + a.rows_per_wg, a.B);
-
-  float bias[CPL], gam[CPL], bet[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    bias[c] = a.b0[CPL * lane + c];
-    gam[c] = LN ? a.gamma[CPL * lane + c] : 1.f;
-    bet[c] = LN ? a.beta[CPL * lane + c] : 0.f;
-  }
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const uint64_t below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
 
   for (int row = r0 + wave; row < r1; row += FW_T / 64) {
-    const float x = a.xs[row], y = a.ys[row], t = a.ts[row];
+    const bool first = row == r0 + wave;
+    const float x = first ? xf : a.xs[row], y = first ? yf : a.ys[row], t = first ? tf : a.ts[row];
     float acc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) acc[c] = bias[c];
