@@ -40,7 +40,6 @@ struct Plan {
   size_t dA, dZ;            // [B][hmax] each
   size_t part, part_floats; // column-sum partials
   size_t dZl[STDADK_MAX_HIDDEN], partl[STDADK_MAX_HIDDEN];   // fused tail: per-layer dZ and partials
-  size_t wT[STDADK_MAX_HIDDEN];                              // fused tail: W_l^T scratch (l >= 1)
   // step-level buffers
   size_t feats; int64_t ldf;           // dense: materialised features
   size_t bw_exp, kpart; int kslabs;    // learnable knots: exp(log_bw) [Ks], per-slab knot partials
@@ -121,7 +120,6 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
   for (int l = 0; l < d->n_hidden; ++l) {
     p->dZl[l] = take((size_t)B * d->hidden[l]);
     p->partl[l] = take((size_t)ceil_div(B, TAIL_MIN_ROWS) * 3 * d->hidden[l]);
-    p->wT[l] = take(l > 0 ? (size_t)d->hidden[l] * d->hidden[l - 1] : 1);
   }
   p->feats = p->psi = p->ypred = p->dY = 0;
   p->ldf = 0; p->ld_psi = 0; p->G = 0;
@@ -489,10 +487,9 @@ struct Ctx {
   // optional second stream: independent kernels of a step fork onto it (hipGraph-capturable
   // fork/join through events); NULL = everything on `st`
   hipStream_t aux = nullptr;
-  bool wt_ready = false;
   int (*fork_after_dz)(Ctx &) = nullptr;   // called by run_backward (fused tail) right after the dZ kernel
   const stdadk_basis_desc *basis = nullptr;
-  bool dw0_forked = false;        // W^T scratch of the fused backward already produced (on aux)
+  bool dw0_forked = false;        // the per-knot gather of dW0^T was forked onto the auxiliary stream
   // extra products C[M][H0] = A^T dZ_0 (reduction over the batch) to run with the dW GEMMs of the
   // fused-tail backward: the temporal / covariate rows of dW0^T on the window path
   int n_extra = 0;
@@ -662,17 +659,11 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
       a.L[l] = tail_layer(c, l);
       a.dZ[l] = ws + pl.dZl[l];
       a.part[l] = ws + pl.partl[l];
-      a.WT[l] = ws + pl.wT[l];
     }
     STDADK_REQUIRE(G->W[L] && G->b[L], STDADK_E_ARG, "mlp_backward: output layer grads NULL");
     a.B = (int)B; a.Wo = P->W[L]; a.Q = Q; a.dY = dY;
     a.act_last = ws + pl.act[L - 1]; a.part_head = part;
     a.layernorm = d->layernorm; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
-    if (!c.wt_ready) {
-      rc = tail_transpose_weights(a, st);
-      if (rc) return rc;
-    }
-    c.wt_ready = false;
     rc = tail_backward(a, st);
     if (rc) return rc;
     c.dz0 = ws + pl.dZl[0];
@@ -1088,10 +1079,6 @@ static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const 
   c.basis = b;
   c.dw0_forked = false;
   if (c.aux) {
-    if (c.wt_ready) {            // the W^T scratch was produced on the auxiliary stream
-      rc = stream_depends(c.st, c.aux, 1);
-      if (rc) return rc;
-    }
     // as soon as dZ is final, the knot-row gather of dW0^T runs on the auxiliary stream beside the
     // dW GEMMs and reductions of the other layers
     c.fork_after_dz = [](Ctx &cc) -> int {
@@ -1226,19 +1213,6 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
   const bool plain = loss_is_plain_mse(c.loss, d->out_dim);
   const int64_t n = B * d->out_dim;
   c.mse_scale = grad_scale; c.mse_dY = c.ws + c.pl.dY; c.mse_loss = loss_sum;
-  if (window && c.aux && tail_enabled() && d->n_hidden > 1 && tail_supported(d, 1)) {
-    // fork: the W^T scratch of the fused backward does not depend on this batch
-    c.P = P;
-    rc = stream_depends(c.aux, (hipStream_t)stream, 0);
-    if (rc) return rc;
-    TailBwdArgs ta;
-    ta.n_layers = d->n_hidden;
-    c.ws = (float *)workspace;
-    for (int l = 0; l < d->n_hidden; ++l) { ta.L[l] = tail_layer(c, l); ta.WT[l] = c.ws + c.pl.wT[l]; }
-    rc = tail_transpose_weights(ta, c.aux);
-    if (rc) return rc;
-    c.wt_ready = true;
-  }
   if (window) {
     // everything between the binning and the weight gradients stays in sorted order
     c.mse_y = c.ws + c.pl.y_s;

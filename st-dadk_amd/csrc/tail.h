@@ -49,14 +49,14 @@ struct TailFwdArgs {
 
 struct TailBwdArgs {
   int n_layers;                 // hidden layers in this launch: model layers first_layer .. first_layer+n-1
-  TailLayer L[TAIL_MAX_LAYERS]; // L[0] is the FIRST of them (its W is not needed: no dA below it)
+  TailLayer L[TAIL_MAX_LAYERS]; // L[0] is the FIRST of them (its W is not needed: no dA below it); W of the
+                                // others is read in place as the [K][N] operand of dA = dZ . W
   int B;
   const float *Wo;              // [Q][h_last]
   int Q;
   const float *dY;              // [B][Q]
   const float *act_last;        // [B][h_last] activations feeding the output layer
   float *part_head;             // [nblk][Q*h_last | Q] partials of dWo then dbo
-  float *WT[TAIL_MAX_LAYERS];   // [hp_l][h_l] scratch: W_l transposed (tail_transpose_weights), l >= 1
   float *dZ[TAIL_MAX_LAYERS];   // [B][h_l] out: gradient w.r.t. the pre-LayerNorm output of layer l
   float *part[TAIL_MAX_LAYERS]; // [nblk][3][h_l] column partials (dgamma, dbeta, db) per workgroup
   int layernorm;
@@ -68,7 +68,6 @@ struct TailBwdArgs {
 bool tail_supported(const stdadk_mlp_desc *d, int first_layer);
 int tail_rows(int64_t B);        // rows per workgroup the launches will use for a batch of B rows
 int tail_forward(const TailFwdArgs &a, hipStream_t st);
-int tail_transpose_weights(const TailBwdArgs &a, hipStream_t st);   // fills a.WT (needs only L[].W/h/hp, WT)
-int tail_backward(const TailBwdArgs &a, hipStream_t st);            // a.WT must be ready
+int tail_backward(const TailBwdArgs &a, hipStream_t st);
 
 }  // namespace stdadk

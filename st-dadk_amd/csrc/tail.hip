@@ -16,8 +16,6 @@ constexpr int NW = 16;                        // waves per workgroup (4 per SIMD
                                               // 16 rows per workgroup, more waves = more loads in flight
 constexpr int TT = 64 * NW;                   // threads per workgroup
 constexpr int MAX_NI = TAIL_MAX_W / 16 / NW;  // N tiles per wave
-constexpr int MAX_MT = TAIL_ROWS / 16;        // 16-row MFMA tiles per workgroup: 1 (small batches: more
-                                              // workgroups than CUs matters) or 2 (weight fragments shared)
 constexpr int ACT_LD = TAIL_MAX_W + 4;        // activation row stride in LDS (floats)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
@@ -50,6 +48,22 @@ __device__ __forceinline__ void load_bfrag(BFrag<NI> &f, const float *__restrict
       const int n = 16 * (wave + NW * i) + c16;         // < N by construction of NI
       f.v[j * NI + i] = *reinterpret_cast<const float4 *>(Wn + (size_t)n * K + kc);
     }
+  }
+}
+
+// Same fragment from a [K][N] row-major operand (N contiguous): nn.Linear's own (out,in) weight read as
+// the B operand of dA = dZ . W — four dword loads (64-byte pieces per 16 lanes) instead of one dwordx4,
+// and no transposed copy of the weights is needed.  Component e of v[j] is k = 32c + 16j + 4q + e, the
+// same k order as the A fragments, so the MFMA stream is unchanged.
+__device__ __forceinline__ void load_bfrag_kn(BFrag<1> &f, const float *__restrict__ Wkn, int N, int K, int c, int wave,
+                                              int c16, int q) {
+  const int n = 16 * wave + c16;                      // < N by the caller's wave < N/16 test
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = 32 * c + 16 * j + 4 * q;
+    const int kc = k < K ? k : 0;
+    const float *b = Wkn + (size_t)kc * N + n;
+    f.v[j] = make_float4(b[0], b[N], b[2 * (size_t)N], b[3 * (size_t)N]);
   }
 }
 
@@ -106,21 +120,26 @@ __device__ __forceinline__ void preload_w(BFrag<1> &f, const float *__restrict__
   if (wave < (N >> 4)) load_bfrag<1>(f, Wn, K, 0, wave, c16, q);
 }
 
-// gemm16 with chunk 0 already in registers (see preload_w)
-template <int MT>
+// gemm16 with chunk 0 already in registers (see preload_w).  KN: the weight operand is [K][N] row-major.
+template <int MT, bool KN = false>
 __device__ __forceinline__ void gemm16_pre(f32x4 (*acc)[MAX_NI], const float *__restrict__ A, const float *__restrict__ Wn,
                                            int N, int K, int wave, int c16, int q, BFrag<1> &f0) {
   if (wave >= (N >> 4)) return;                 // scalar: this wave has no N tile in a narrow layer
   const int nchunk = (K + 31) >> 5;
   BFrag<1> f1;
   for (int c = 0; c < nchunk; c += 2) {
-    if (c + 1 < nchunk) load_bfrag<1>(f1, Wn, K, c + 1, wave, c16, q);
+    if (c + 1 < nchunk) { if (KN) load_bfrag_kn(f1, Wn, N, K, c + 1, wave, c16, q); else load_bfrag<1>(f1, Wn, K, c + 1, wave, c16, q); }
     mma_chunk<1, MT>(acc, f0, A, K, c, c16, q);
     if (c + 1 < nchunk) {
-      if (c + 2 < nchunk) load_bfrag<1>(f0, Wn, K, c + 2, wave, c16, q);
+      if (c + 2 < nchunk) { if (KN) load_bfrag_kn(f0, Wn, N, K, c + 2, wave, c16, q); else load_bfrag<1>(f0, Wn, K, c + 2, wave, c16, q); }
       mma_chunk<1, MT>(acc, f1, A, K, c + 1, c16, q);
     }
   }
+}
+
+__device__ __forceinline__ void preload_w_kn(BFrag<1> &f, const float *__restrict__ Wkn, int N, int K, int wave, int c16,
+                                             int q) {
+  if (wave < (N >> 4)) load_bfrag_kn(f, Wkn, N, K, 0, wave, c16, q);
 }
 
 // acc[mt][i] (rows 16 mt.., N-tile t = wave + NW i) += A[R x K] (LDS, row stride ACT_LD) * Wn[N x K]^T where Wn is
@@ -425,7 +444,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
     const TailLayer &L = a.L[li];
     const int h = L.h;
     BFrag<1> wpre;
-    if (li > 0) preload_w(wpre, a.WT[li], L.hp, h, wave, c16, q);     // for the dA GEMM at the end of this pass
+    if (li > 0) preload_w_kn(wpre, L.W, L.hp, h, wave, c16, q);       // for the dA GEMM at the end of this pass
     // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows RPW*w .. of this wave.  Its global inputs
     // (xhat rows, gamma, beta, rstd) were requested one phase early (ln_inputs below).
     float pg[4], pb[4], pz[4];
@@ -505,7 +524,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
       for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ln_inputs(a.L[li - 1]);        // consumed after the GEMM, in the next pass
     lds_barrier();                 // every wave's dZ rows are in `cur`
-    gemm16_pre<MT>(acc, cur, a.WT[li], hp, h, wave, c16, q, wpre);
+    gemm16_pre<MT, true>(acc, cur, L.W, hp, h, wave, c16, q, wpre);
 #pragma unroll
     for (int i = 0; i < MAX_NI; ++i) {
       const int t = wave + NW * i;
@@ -519,22 +538,6 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
     lds_barrier();
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
-}
-
-// WT[n][k] = W[k][n] for the tail layers (h x hp -> hp x h), one launch for all of them
-struct TransArgs { int n; const float *W[TAIL_MAX_LAYERS]; float *WT[TAIL_MAX_LAYERS]; int h[TAIL_MAX_LAYERS], hp[TAIL_MAX_LAYERS]; };
-__global__ __launch_bounds__(256) void tail_transpose_kernel(TransArgs a) {
-  __shared__ float tile[32][33];
-  const int li = blockIdx.z;
-  const int h = a.h[li], hp = a.hp[li];
-  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;     // W[k][n], k < h, n < hp
-  if (k0 >= h || n0 >= hp) return;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8)
-    tile[r][tx] = (k0 + r < h && n0 + tx < hp) ? a.W[li][(size_t)(k0 + r) * hp + n0 + tx] : 0.f;
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8)
-    if (n0 + r < hp && k0 + tx < h) a.WT[li][(size_t)(n0 + r) * h + k0 + tx] = tile[tx][r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -594,26 +597,6 @@ static int launch_bwd(const TailBwdArgs &a, hipStream_t st) {
   }
   STDADK_LAUNCH_NAMED("tail_bwd_kernel", (tail_bwd_kernel<MT>), dim3((unsigned)ceil_div(a.B, R)), dim3(TT), bwd_lds(R), st, a);
   STDADK_CHECK_LAUNCH("tail_backward");
-  return 0;
-}
-
-// WT[l] = W_l^T for the layers whose dA product the backward kernel runs (l >= 1); may run on another
-// stream than tail_backward as long as it has finished before.
-int tail_transpose_weights(const TailBwdArgs &a, hipStream_t st) {
-  if (a.n_layers <= 1) return 0;
-  TransArgs t;
-  t.n = a.n_layers - 1;
-  int hmax = 0, hpmax = 0;
-  for (int li = 1; li < a.n_layers; ++li) {
-    t.W[li - 1] = a.L[li].W; t.WT[li - 1] = a.WT[li];
-    t.h[li - 1] = a.L[li].h; t.hp[li - 1] = a.L[li].hp;
-    hmax = a.L[li].h > hmax ? a.L[li].h : hmax;
-    hpmax = a.L[li].hp > hpmax ? a.L[li].hp : hpmax;
-  }
-  for (int li = t.n; li < TAIL_MAX_LAYERS; ++li) { t.W[li] = nullptr; t.WT[li] = nullptr; t.h[li] = t.hp[li] = 0; }
-  STDADK_LAUNCH(tail_transpose_kernel, dim3((unsigned)ceil_div(hpmax, 32), (unsigned)ceil_div(hmax, 32), (unsigned)t.n),
-                dim3(256), 0, st, t);
-  STDADK_CHECK_LAUNCH("tail_transpose");
   return 0;
 }
 
