@@ -369,6 +369,23 @@ class TrainStep:
         self.step_count += 1
         self.rows_seen += B
 
+    def run_epoch(self, dataset, batch_size, generator=None, shuffle=True):
+        """One pass over a `stnf.dataio.device_dataset.DeviceDataset` in shuffled mini-batches (the
+        epoch loop of scripts/train_st_interp.py:608-724 with the set resident in HBM): every step
+        announces the next batch so that its preparation overlaps the running step.  Returns the mean
+        batch objective of the epoch (ONE host sync)."""
+        batches = dataset.epoch_batches(batch_size, generator=generator, shuffle=shuffle)
+        world_rows = None
+        for i, idx in enumerate(batches):
+            nxt = batches[i + 1] if i + 1 < len(batches) else None
+            if self.distributed:
+                # full batches: every rank has batch_size rows; only the ragged last one asks the group
+                world_rows = (idx.numel() * self.world if idx.numel() == batch_size
+                              else D.global_rows(idx.numel(), self.pg, device=self.dev))
+            self.step_indexed(dataset.coords, dataset.t, dataset.y, idx, X_all=dataset.X, global_rows=world_rows,
+                              next_idx=nxt)
+        return self.mean_loss()
+
     def _step_pipelined(self, coords_all, t_all, y_all, Xa, idx, next_idx, B, global_rows):
         """Step on a batch that was (or is now) binned into one of two workspaces, and batch
         preparation of `next_idx` on the side stream into the other one."""

@@ -1288,3 +1288,31 @@ def test_coarse_knots_learnable_large_batch():
     assert np.abs(yp.detach().cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
     for k in go:
         assert rel_l2(outs[0][k].cpu().numpy(), go[k]) <= 2e-5, (k, rel_l2(outs[0][k].cpu().numpy(), go[k]))
+
+
+def test_run_epoch_equals_manual_loop():
+    """TrainStep.run_epoch over a DeviceDataset (pipelined batch preparation, ragged last batch) ==
+    the plain step_indexed loop over the same index slices, bit for bit."""
+    from stnf.engine import TrainStep
+    from stnf.dataio.device_dataset import DeviceDataset
+    d = dev()
+    rs = np.random.RandomState(21)
+    n = 1000
+    ds = DeviceDataset(torch.from_numpy(rs.uniform(0, 1, (n, 2)).astype(np.float32)).to(d),
+                       torch.from_numpy(rs.uniform(0, 1, (n, 1)).astype(np.float32)).to(d),
+                       torch.from_numpy(rs.standard_normal((n, 1)).astype(np.float32)).to(d))
+    res = []
+    for mode in ("epoch", "manual"):
+        m = build_model(cases.MODEL_CASES["default227"])
+        m.train()
+        eng = TrainStep(m, lr=1e-3, ema_decay=0.99, max_batch=256)
+        gen = torch.Generator(device=d).manual_seed(3)
+        if mode == "epoch":
+            loss = eng.run_epoch(ds, 256, generator=gen)
+        else:
+            for idx in ds.epoch_batches(256, generator=gen):
+                eng.step_indexed(ds.coords, ds.t, ds.y, idx)
+            loss = eng.mean_loss()
+        res.append((eng.flat.clone(), loss))
+    assert torch.equal(res[0][0], res[1][0])
+    assert abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[0][1])
