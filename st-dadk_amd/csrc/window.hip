@@ -18,7 +18,6 @@
 namespace stdadk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4m __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
 // observation binning
@@ -343,14 +342,12 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int H = 64 * CPL;
   constexpr int NW = FW_T / 64;
-  static_assert(NW == 16, "the temporal MFMA product takes the 16 rows of a round as its M dimension");
   const int Kt = a.g.Kt;
   float *Wt = smem;                                   // [Kt][H] temporal rows of W0^T
   float *lphi = Wt + (size_t)Kt * H;                  // [NW][LIST]
   int *lk = reinterpret_cast<int *>(lphi + NW * LIST); // [NW][LIST]
   float *lpsi = reinterpret_cast<float *>(lk + NW * LIST);  // [NW][Kt_pad]
   const int Kt_pad = (Kt + 3) & ~3;
-  float *zt = lpsi + NW * Kt_pad;                           // [NW][H] temporal part of the round's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D0 = a.g.p + a.g.Ks;                      // first temporal row of W0^T
   // XCD-aware chunking: workgroups w and w+8 share an XCD (round-robin dispatch), so XCD x walks
@@ -383,15 +380,9 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const uint64_t below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
 
-  // rounds of NW rows (one per wave); every wave runs every round, because the temporal block of a
-  // round is ONE small MFMA product of the workgroup ([NW x Kt] psi by [Kt x H] rows of W0^T) between
-  // two workgroup barriers
-  for (int rb = r0; rb < r1; rb += NW) {
-    const int row = rb + wave;
-    const bool valid = row < r1;                      // wave-uniform
-    const bool first = rb == r0;
-    const int rowc = valid ? row : r1 - 1;
-    const float x = first ? xf : a.xs[rowc], y = first ? yf : a.ys[rowc], t = first ? tf : a.ts[rowc];
+  for (int row = r0 + wave; row < r1; row += FW_T / 64) {
+    const bool first = row == r0 + wave;
+    const float x = first ? xf : a.xs[row], y = first ? yf : a.ys[row], t = first ? tf : a.ts[row];
     float acc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) acc[c] = bias[c];
@@ -421,7 +412,7 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
     // ---- spatial levels through the per-wave candidate list (fixed knots: three levels at a time,
     // 6 x 6 candidates each; free knots: one level at a time, (2R)^2 candidates in passes of 64)
     constexpr int LSTEP = FREE ? 1 : 3;
-    for (int l0 = 0; valid && l0 < a.g.n_levels; l0 += LSTEP) {
+    for (int l0 = 0; l0 < a.g.n_levels; l0 += LSTEP) {
       int n = 0;
       const int l1 = min(l0 + LSTEP, a.g.n_levels);
       for (int l = l0; FREE && l < l1; ++l) {
@@ -512,38 +503,16 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- temporal basis.  psi of the round's rows goes to LDS; wave w then forms columns 16w..16w+15 of
-    // Z_t = psi . Wt for ALL rows of the round on the matrix cores (each wave reads 16 columns of Wt, not
-    // all H of them for its own row: 15x less LDS traffic than per-row FMAs), and the rows come back
-    // through LDS to the waves that own them.
-    for (int j = lane; j < Kt_pad; j += 64) {
-      const float v = (valid && j < Kt) ? psi_eval(t, a.g.t_centers[min(j, Kt - 1)], a.g.t_bw[min(j, Kt - 1)]) : 0.f;
+    // ---- temporal basis: rows from LDS
+    for (int j = lane; j < Kt; j += 64) {
+      float v = psi_eval(t, a.g.t_centers[j], a.g.t_bw[j]);
       my_psi[j] = v;
-      if (valid && j < Kt) a.psi[(size_t)row * a.ld_psi + j] = v;
+      a.psi[(size_t)row * a.ld_psi + j] = v;
     }
-    if (valid)
-      for (int j = Kt + lane; j < a.ld_psi; j += 64) a.psi[(size_t)row * a.ld_psi + j] = 0.f;
-    __syncthreads();
-    if (wave < H / 16) {
-      const int c16 = lane & 15, q = lane >> 4;
-      f32x4m z4 = {0.f, 0.f, 0.f, 0.f};
-      for (int k0 = 0; k0 < Kt_pad; k0 += 4) {
-        const int k = k0 + q;
-        const float av = lpsi[c16 * Kt_pad + k];                       // psi[row c16][k]
-        const float bv = k < Kt ? Wt[(size_t)k * H + 16 * wave + c16] : 0.f;
-        z4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, z4, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) zt[(4 * q + r) * H + 16 * wave + c16] = z4[r];   // rows 4q+r, column c16
-    }
-    __syncthreads();
-    {
-      const typename VecT<CPL>::T zv = *reinterpret_cast<const typename VecT<CPL>::T *>(zt + (size_t)wave * H + CPL * lane);
-      const float *zf = reinterpret_cast<const float *>(&zv);
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) acc[c] += zf[c];
-    }
-    if (!valid) continue;
+    for (int j = Kt + lane; j < a.ld_psi; j += 64) a.psi[(size_t)row * a.ld_psi + j] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < Kt; ++j) fma_row<CPL>(acc, my_psi[j], Wt + (size_t)j * H + CPL * lane);
+    __builtin_amdgcn_wave_barrier();
 
     // ---- LayerNorm -> ReLU -> Dropout (row-local: this wave owns the whole row)
     float mean = 0.f, rs = 1.f;
@@ -623,7 +592,7 @@ bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt) {
 template <int CPL, bool LN, int BASIS, bool FREE>
 static int launch_fwd_t(const L1FwdArgs &a, hipStream_t st) {
   const int Kt_pad = (a.g.Kt + 3) & ~3;
-  size_t lds = ((size_t)a.g.Kt * 64 * CPL + (FW_T / 64) * (LIST * 2 + Kt_pad + 64 * CPL)) * sizeof(float);
+  size_t lds = ((size_t)a.g.Kt * 64 * CPL + (FW_T / 64) * (LIST * 2 + Kt_pad)) * sizeof(float);
   auto kern = l1_window_fwd_kernel<CPL, LN, BASIS, FREE>;
   // raise the dynamic-LDS cap when a launch needs more than any before it (never inside a stream
   // capture: the engine runs its first step eagerly)
