@@ -1257,7 +1257,7 @@ extern "C" int stdadk_bin_batch_f32(const stdadk_basis_desc *b, const stdadk_mlp
   // with the step's one-workgroup-per-CU kernels; a single 1024-thread workgroup would take a whole CU
   // away from them for its entire duration
   return bin_obs(coords_all, t_all, y_cols > 0 ? y_all : nullptr, y_cols, X_all, b->p, (int)B, c.pl.G, bb,
-                 (hipStream_t)stream, idx, getenv("STDADK_BIN_BATCH_SMALL") == nullptr);
+                 (hipStream_t)stream, idx, true);
 }
 
 extern "C" int stdadk_train_fwd_bwd_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
