@@ -664,6 +664,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     a.B = (int)B; a.Wo = P->W[L]; a.Q = Q; a.dY = dY;
     a.act_last = ws + pl.act[L - 1]; a.part_head = part;
     a.layernorm = d->layernorm; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
+    { const char *e = getenv("STDADK_TAIL_BWD_STAMPS"); a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     rc = tail_backward(a, st);
     if (rc) return rc;
     c.dz0 = ws + pl.dZl[0];

@@ -63,6 +63,7 @@ struct TailBwdArgs {
   float drop_p;
   uint64_t seed;
   const int *step_dev;
+  unsigned long long *stamps;   // -DSTDADK_DIAG builds only (see TailFwdArgs), else NULL
 };
 
 bool tail_supported(const stdadk_mlp_desc *d, int first_layer);

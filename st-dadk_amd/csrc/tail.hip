@@ -369,6 +369,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = blockIdx.x * R;
+  STAMP(0);
   // Global inputs of a layer's LayerNorm-backward phase: all loads issued together from clamped
   // addresses, unconditionally (one L2 round trip), and one phase EARLY — for the last layer right here
   // (hidden behind the head phase),
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   float *cur = d0, *nxt = d1;
+  STAMP(1);                     // head phase done (dA of the last layer, dWo / dbo partials)
 
   for (int li = a.n_layers - 1; li >= 0; --li) {
     const TailLayer &L = a.L[li];
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
         pbase[k * h + tid] = t;
       }
     }
+    STAMP(2 + 3 * (a.n_layers - 1 - li));      // LayerNorm-backward phase + column partials of this pass
     if (li == 0) break;   // (the partials above are published by the barrier inside part (b) / kernel end)
     // ---- (b) dA_prev[16 x hp] = dZ[16 x h] W[h x hp], with W^T ([hp][h], K contiguous) as the B operand
     const int hp = L.hp;
@@ -525,6 +528,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
     ln_inputs(a.L[li - 1]);        // consumed after the GEMM, in the next pass
     lds_barrier();                 // every wave's dZ rows are in `cur`
     gemm16_pre<MT, true>(acc, cur, L.W, hp, h, wave, c16, q, wpre);
+    STAMP(3 + 3 * (a.n_layers - 1 - li));      // dA GEMM of this pass
 #pragma unroll
     for (int i = 0; i < MAX_NI; ++i) {
       const int t = wave + NW * i;
@@ -536,6 +540,7 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
       }
     }
     lds_barrier();
+    STAMP(4 + 3 * (a.n_layers - 1 - li));      // dA tile stored + barrier
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
 }
