@@ -86,28 +86,11 @@ __device__ __forceinline__ void mma_chunk(f32x4 (*acc)[MAX_NI], const BFrag<NI> 
           const float4 bv = f.v[j * NI + i];
           const float bf[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)      // every weight fragment feeds both row tiles
+          for (int mt = 0; mt < MT; ++mt) {    // every weight fragment feeds both row tiles
             acc[mt][i] = mfma16(af[mt][e], bf[e], acc[mt][i]);
+          }
         }
       }
-    }
-  }
-}
-
-template <int NI, int MT>
-__device__ __forceinline__ void gemm16_ni(f32x4 (*acc)[MAX_NI], const float *__restrict__ A, const float *__restrict__ Wn,
-                                          int K, int wave, int c16, int q) {
-  const int nchunk = (K + 31) >> 5;
-  // two 32-deep chunks in flight per wave (four measured no faster: the phase is paced by the shared
-  // MFMA pipe at 4 waves per SIMD, not by the load round trips)
-  BFrag<NI> f0, f1;
-  load_bfrag<NI>(f0, Wn, K, 0, wave, c16, q);
-  for (int c = 0; c < nchunk; c += 2) {
-    if (c + 1 < nchunk) load_bfrag<NI>(f1, Wn, K, c + 1, wave, c16, q);
-    mma_chunk<NI, MT>(acc, f0, A, K, c, c16, q);
-    if (c + 1 < nchunk) {
-      if (c + 2 < nchunk) load_bfrag<NI>(f0, Wn, K, c + 2, wave, c16, q);
-      mma_chunk<NI, MT>(acc, f1, A, K, c + 1, c16, q);
     }
   }
 }
@@ -142,19 +125,9 @@ __device__ __forceinline__ void preload_w_kn(BFrag<1> &f, const float *__restric
   if (wave < (N >> 4)) load_bfrag_kn(f, Wkn, N, K, 0, wave, c16, q);
 }
 
-// acc[mt][i] (rows 16 mt.., N-tile t = wave + NW i) += A[R x K] (LDS, row stride ACT_LD) * Wn[N x K]^T where Wn is
-// row-major [N][K] in global memory (K contiguous).  M = 16 is the GEMV-like regime: every wave
-// streams ITS OWN slice of W straight into VGPRs (no LDS staging, no workgroup barrier in the K
-// loop), two 32-deep chunks in flight, 64-byte row pieces per lane group.
-template <int MT>
-__device__ __forceinline__ void gemm16(f32x4 (*acc)[MAX_NI], const float *__restrict__ A, const float *__restrict__ Wn, int N,
-                                       int K, int wave, int c16, int q) {
-  const int NT = N >> 4;
-  const int ni = (NT - wave + NW - 1) / NW;   // tiles wave, wave+NW, ... < NT   (wave is scalar)
-  static_assert(MAX_NI <= 2, "dispatch below assumes at most 2 tiles per wave");
-  if (MAX_NI >= 2 && ni >= 2) gemm16_ni<(MAX_NI >= 2 ? 2 : 1), MT>(acc, A, Wn, K, wave, c16, q);
-  else if (ni >= 1) gemm16_ni<1, MT>(acc, A, Wn, K, wave, c16, q);
-}
+// GEMM of a phase: acc[mt][0] (rows 16 mt.., N tile of this wave) += A[R x K] (LDS, row stride ACT_LD) * W.
+// M = 16..64 rows is the GEMV-like regime: every wave streams ITS OWN slice of W straight into VGPRs (no
+// LDS staging, no workgroup barrier in the K loop), two 32-deep chunks in flight.
 
 // ---------------------------------------------------------------------------------------------
 // forward
