@@ -479,6 +479,10 @@ struct Ctx {
   float *mse_dY = nullptr;
   float *mse_loss = nullptr;
   bool mse_done = false;        // set by run_forward when the loss was fused into the tail kernel
+  // fused training step: run_forward parks the tail launch here and run_backward issues it together
+  // with the backward chain as ONE kernel (the tail of a row tile is row-local through the loss)
+  bool fuse_tail = false, pend_valid = false;
+  TailFwdArgs pend;
   bool log_bw = false;          // basis->s_bw holds log-bandwidths (learnable knots)
   const int64_t *idx = nullptr; // window path: the batch is rows idx[b] of the resident observation arrays
   bool prebinned = false;       // window path: stdadk_bin_batch_f32 already filled the workspace's bins
@@ -612,6 +616,7 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
     a.layernorm = d->layernorm; a.eps = d->ln_eps; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
     c.mse_done = c.mse_y != nullptr;
     { const char *e = getenv("STDADK_TAIL_STAMPS"); a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
+    if (c.fuse_tail && c.mse_done) { c.pend = a; c.pend_valid = true; return 0; }
     return tail_forward(a, st);
   }
   for (int l = l0; l < L; ++l) {
@@ -665,7 +670,12 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     a.act_last = ws + pl.act[L - 1]; a.part_head = part;
     a.layernorm = d->layernorm; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
     { const char *e = getenv("STDADK_TAIL_BWD_STAMPS"); a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
-    rc = tail_backward(a, st);
+    if (c.pend_valid) {
+      c.pend_valid = false;
+      rc = tail_forward_backward(c.pend, a, st);
+    } else {
+      rc = tail_backward(a, st);
+    }
     if (rc) return rc;
     c.dz0 = ws + pl.dZl[0];
     if (c.fork_after_dz) {       // dZ of every layer is final: independent consumers may start now
@@ -1214,6 +1224,9 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
   const bool plain = loss_is_plain_mse(c.loss, d->out_dim);
   const int64_t n = B * d->out_dim;
   c.mse_scale = grad_scale; c.mse_dY = c.ws + c.pl.dY; c.mse_loss = loss_sum;
+  // one launch for the forward and backward chains of the tail when nothing has to read the
+  // predictions in between (window path: the un-permute of y_pred) and the loss is fused
+  c.fuse_tail = getenv("STDADK_NO_TAIL_FWD_BWD") == nullptr && !(window && y_pred);
   if (window) {
     // everything between the binning and the weight gradients stays in sorted order
     c.mse_y = c.ws + c.pl.y_s;
@@ -1225,7 +1238,9 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
                                c.ws + c.pl.dY, loss_sum, c.st);
       if (rc) return rc;
     }
-    return step_backward(c, b, true, c.ws + c.pl.dY, true);
+    rc = step_backward(c, b, true, c.ws + c.pl.dY, true);
+    STDADK_REQUIRE(rc || !c.pend_valid, STDADK_E_ARG, "train_fwd_bwd: the parked tail launch was never issued");
+    return rc;
   }
   float *yp = y_pred ? y_pred : c.ws + c.pl.ypred;
   c.mse_y = y;
@@ -1236,7 +1251,9 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
                : launch_loss(c.loss, yp, y, B, d->out_dim, grad_scale, c.ws + c.pl.dY, loss_sum, c.st);
     if (rc) return rc;
   }
-  return step_backward(c, b, false, c.ws + c.pl.dY, false);
+  rc = step_backward(c, b, false, c.ws + c.pl.dY, false);
+  STDADK_REQUIRE(rc || !c.pend_valid, STDADK_E_ARG, "train_fwd_bwd: the parked tail launch was never issued");
+  return rc;
 }
 
 extern "C" int stdadk_bin_batch_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,

@@ -70,5 +70,7 @@ bool tail_supported(const stdadk_mlp_desc *d, int first_layer);
 int tail_rows(int64_t B);        // rows per workgroup the launches will use for a batch of B rows
 int tail_forward(const TailFwdArgs &a, hipStream_t st);
 int tail_backward(const TailBwdArgs &a, hipStream_t st);
+// training: forward (with the loss) and backward of every row tile in one launch
+int tail_forward_backward(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st);
 
 }  // namespace stdadk

@@ -138,11 +138,9 @@ __device__ __forceinline__ void preload_w_kn(BFrag<1> &f, const float *__restric
 #define STAMP(i) do { } while (0)
 #endif
 template <int MT>
-__global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
+__device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem, float *red) {
   constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float *act0 = smem, *act1 = smem + R * ACT_LD;
-  __shared__ float red[TT / 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
   const int q = lane >> 4, c16 = lane & 15;
@@ -329,9 +327,15 @@ __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
 // backward (data path): dA / dZ of every hidden layer + column partials for dgamma, dbeta, db
 // ---------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
-  constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
+__global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[TT / 64];
+  tail_fwd_body<MT>(a, smem, red);
+}
+
+template <int MT>
+__device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem) {
+  constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
   float *d0 = smem, *d1 = smem + R * ACT_LD;
   // column-partial scratch [3][NW][256]: with 64 rows the spare activation buffer is large enough and
   // free during the LayerNorm phase, so it is aliased there instead of taking another 48 KiB
@@ -518,6 +522,26 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   }
 }
 
+template <int MT>
+__global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  tail_bwd_body<MT>(a, smem);
+}
+
+// Training step: the forward chain, the loss and the backward chain of a row tile are all row-local, so
+// one workgroup runs them back to back in ONE launch (saves a launch + drain and lets the backward find
+// what the forward just wrote in L2).  The forward's global stores (xhat, act, rstd, dY) are complete
+// and visible to the whole workgroup after the __syncthreads() (vmcnt(0) + barrier); none of those lines
+// was read by this CU earlier in the launch, so no stale copy can sit in its L1.
+template <int MT>
+__global__ __launch_bounds__(TT) void tail_fwd_bwd_kernel(TailFwdArgs f, TailBwdArgs b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[TT / 64];
+  tail_fwd_body<MT>(f, smem, red);
+  __syncthreads();
+  tail_bwd_body<MT>(b, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 bool tail_supported(const stdadk_mlp_desc *d, int first_layer) {
   if (first_layer < 1 || d->n_hidden < 1) return false;
@@ -576,6 +600,27 @@ static int launch_bwd(const TailBwdArgs &a, hipStream_t st) {
   STDADK_LAUNCH_NAMED("tail_bwd_kernel", (tail_bwd_kernel<MT>), dim3((unsigned)ceil_div(a.B, R)), dim3(TT), bwd_lds(R), st, a);
   STDADK_CHECK_LAUNCH("tail_backward");
   return 0;
+}
+
+template <int MT>
+static int launch_fwd_bwd(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st) {
+  constexpr int R = 16 * MT;
+  const size_t lds = fwd_lds(R) > bwd_lds(R) ? fwd_lds(R) : bwd_lds(R);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_bwd_kernel<MT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("tail_forward_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  STDADK_LAUNCH_NAMED("tail_fwd_bwd_kernel", (tail_fwd_bwd_kernel<MT>), dim3((unsigned)ceil_div(f.B, R)), dim3(TT), lds, st, f, b);
+  STDADK_CHECK_LAUNCH("tail_forward_backward");
+  return 0;
+}
+
+int tail_forward_backward(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st) {
+  const int r = tail_rows(f.B);
+  return r == 64 ? launch_fwd_bwd<4>(f, b, st) : (r == 32 ? launch_fwd_bwd<2>(f, b, st) : launch_fwd_bwd<1>(f, b, st));
 }
 
 int tail_backward(const TailBwdArgs &a, hipStream_t st) {
