@@ -122,6 +122,10 @@ def kernel_work(name, B, D, H, P_flat, nnz_pairs, Kt, Q=1):
         return "mfma", 2.0 * nnz_pairs * H[0], "flop"    # dW0^T rows: one fma per non-zero (obs,knot) x H
     if "l1_window_fwd_kernel" in name:
         return "mfma", 2.0 * (nnz_pairs + B * Kt) * H[0], "flop"
+    if "l1_tail_kernel" in name:
+        # layer 0 on the window path + forward and backward of the layers after it, in one launch
+        fl = sum(2.0 * B * H[i] * H[i - 1] for i in range(1, len(H))) + 2.0 * B * H[-1] * Q
+        return "mfma", 2.0 * fl + 2.0 * (nnz_pairs + B * Kt) * H[0], "flop"
     if "tail_fwd_bwd_kernel" in name:
         # forward z = a W^T and backward dA = dZ W of the layers after the first, in one launch
         fl = sum(2.0 * B * H[i] * H[i - 1] for i in range(1, len(H))) + 2.0 * B * H[-1] * Q

@@ -483,6 +483,9 @@ struct Ctx {
   // with the backward chain as ONE kernel (the tail of a row tile is row-local through the loss)
   bool fuse_tail = false, pend_valid = false;
   TailFwdArgs pend;
+  bool l1_pend_valid = false;   // window path, B <= 4096: the layer-0 launch is parked as well
+  L1FwdArgs l1_pend;
+  int l1_basis = 0;
   bool log_bw = false;          // basis->s_bw holds log-bandwidths (learnable knots)
   const int64_t *idx = nullptr; // window path: the batch is rows idx[b] of the resident observation arrays
   bool prebinned = false;       // window path: stdadk_bin_batch_f32 already filled the workspace's bins
@@ -672,7 +675,12 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     { const char *e = getenv("STDADK_TAIL_BWD_STAMPS"); a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     if (c.pend_valid) {
       c.pend_valid = false;
-      rc = tail_forward_backward(c.pend, a, st);
+      if (c.l1_pend_valid) {
+        c.l1_pend_valid = false;
+        rc = l1_tail_launch(c.l1_pend, c.l1_basis, d->layernorm != 0, c.pend, a, st);
+      } else {
+        rc = tail_forward_backward(c.pend, a, st);
+      }
     } else {
       rc = tail_backward(a, st);
     }
@@ -913,6 +921,13 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
   a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
   a.rows_per_wg = 0; a.n_wg = 0;
   STDADK_REQUIRE(a.W0T && a.b0, STDADK_E_ARG, "window forward: layer 0 weights NULL");
+  // fused training step at <= 16 rows per CU: park this launch too; run_backward issues layer 0, the tail
+  // forward, the loss and the tail backward as ONE kernel (every one of them is row-local)
+  if (c.fuse_tail && c.mse_y && !c.masks && tail_enabled() && c.d->n_hidden >= 1 && tail_supported(c.d, 1) &&
+      tail_rows(c.B) == 16 && l1_tail_supported(c.B, a.H) && getenv("STDADK_NO_L1_TAIL") == nullptr) {
+    c.l1_pend = a; c.l1_pend_valid = true; c.l1_basis = b->basis;
+    return 0;
+  }
   return l1_window_forward(a, b->basis, c.d->layernorm != 0, c.st);
 }
 
@@ -1239,7 +1254,8 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
       if (rc) return rc;
     }
     rc = step_backward(c, b, true, c.ws + c.pl.dY, true);
-    STDADK_REQUIRE(rc || !c.pend_valid, STDADK_E_ARG, "train_fwd_bwd: the parked tail launch was never issued");
+    STDADK_REQUIRE(rc || (!c.pend_valid && !c.l1_pend_valid), STDADK_E_ARG,
+                   "train_fwd_bwd: a parked launch was never issued");
     return rc;
   }
   float *yp = y_pred ? y_pred : c.ws + c.pl.ypred;

@@ -74,3 +74,12 @@ int tail_backward(const TailBwdArgs &a, hipStream_t st);
 int tail_forward_backward(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st);
 
 }  // namespace stdadk
+#include "window.h"
+namespace stdadk {
+// training, B <= 4096 on the window path: layer 0 + the tail forward + loss + tail backward in one launch
+// (fused_step.hip); rows_per_wg / n_wg of `l` are set by the callee
+bool l1_tail_supported(int64_t B, int H);
+int l1_tail_launch(const L1FwdArgs &l, int basis, bool layernorm, const TailFwdArgs &f, const TailBwdArgs &b,
+                   hipStream_t st);
+
+}  // namespace stdadk

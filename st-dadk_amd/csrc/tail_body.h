@@ -1,0 +1,513 @@
+// Bodies of the fused MLP-tail kernels (see tail.h / tail.hip), shared by their own kernels and by the
+// fused training-step kernel (fused_step.hip).  `tile` = index of the row tile (R rows) a workgroup carries.
+#pragma once
+#include "tail.h"
+
+namespace stdadk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NW = 16;                        // waves per workgroup (4 per SIMD): the phases are latency-bound at
+                                              // 16 rows per workgroup, more waves = more loads in flight
+constexpr int TT = 64 * NW;                   // threads per workgroup
+constexpr int MAX_NI = TAIL_MAX_W / 16 / NW;  // N tiles per wave
+constexpr int ACT_LD = TAIL_MAX_W + 4;        // activation row stride in LDS (floats)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// GLOBAL store (vmcnt(0)); nothing in these kernels reads global data written by another wave.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+
+template <int NI>
+struct BFrag { float4 v[2 * NI]; };     // [j*NI + i] : chunk fragment of this lane
+
+// Loads are UNCONDITIONAL from clamped (always valid) addresses and never masked in registers: a
+// conditional load gets its own branch + vmcnt(0), and a select on the loaded value drags the wait
+// in front of the MFMAs of the previous chunk.  The number of N tiles of this wave (NI) is a
+// template parameter and the K-half test is scalar, so the MFMA stream has no exec-masked branches.
+template <int NI>
+__device__ __forceinline__ void load_bfrag(BFrag<NI> &f, const float *__restrict__ Wn, int K, int c, int wave,
+                                           int c16, int q) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = 32 * c + 16 * j + 4 * q;
+    const int kc = k < K ? k : 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = 16 * (wave + NW * i) + c16;         // < N by construction of NI
+      f.v[j * NI + i] = *reinterpret_cast<const float4 *>(Wn + (size_t)n * K + kc);
+    }
+  }
+}
+
+// Same fragment from a [K][N] row-major operand (N contiguous): nn.Linear's own (out,in) weight read as
+// the B operand of dA = dZ . W — four dword loads (64-byte pieces per 16 lanes) instead of one dwordx4,
+// and no transposed copy of the weights is needed.  Component e of v[j] is k = 32c + 16j + 4q + e, the
+// same k order as the A fragments, so the MFMA stream is unchanged.
+__device__ __forceinline__ void load_bfrag_kn(BFrag<1> &f, const float *__restrict__ Wkn, int N, int K, int c, int wave,
+                                              int c16, int q) {
+  const int n = 16 * wave + c16;                      // < N by the caller's wave < N/16 test
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = 32 * c + 16 * j + 4 * q;
+    const int kc = k < K ? k : 0;
+    const float *b = Wkn + (size_t)kc * N + n;
+    f.v[j] = make_float4(b[0], b[N], b[2 * (size_t)N], b[3 * (size_t)N]);
+  }
+}
+
+template <int NI, int MT>
+__device__ __forceinline__ void mma_chunk(f32x4 (*acc)[MAX_NI], const BFrag<NI> &f, const float *__restrict__ A, int K,
+                                          int c, int c16, int q) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (32 * c + 16 * j < K) {          // scalar: K is a multiple of 16, a 16-deep half is all in or out
+      float af[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 av = *reinterpret_cast<const float4 *>(A + (16 * mt + c16) * ACT_LD + 32 * c + 16 * j + 4 * q);
+        af[mt][0] = av.x; af[mt][1] = av.y; af[mt][2] = av.z; af[mt][3] = av.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const float4 bv = f.v[j * NI + i];
+          const float bf[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {    // every weight fragment feeds both row tiles
+            acc[mt][i] = mfma16(af[mt][e], bf[e], acc[mt][i]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// The first 32-deep weight chunk of a GEMM phase, requested one phase EARLY (before the row-local
+// LayerNorm / input phase that precedes the GEMM) so that its L2 round trip is hidden behind that phase.
+static_assert(MAX_NI == 1, "the preloaded variant below assumes one N tile per wave");
+__device__ __forceinline__ void preload_w(BFrag<1> &f, const float *__restrict__ Wn, int N, int K, int wave, int c16,
+                                          int q) {
+  if (wave < (N >> 4)) load_bfrag<1>(f, Wn, K, 0, wave, c16, q);
+}
+
+// gemm16 with chunk 0 already in registers (see preload_w).  KN: the weight operand is [K][N] row-major.
+template <int MT, bool KN = false>
+__device__ __forceinline__ void gemm16_pre(f32x4 (*acc)[MAX_NI], const float *__restrict__ A, const float *__restrict__ Wn,
+                                           int N, int K, int wave, int c16, int q, BFrag<1> &f0) {
+  if (wave >= (N >> 4)) return;                 // scalar: this wave has no N tile in a narrow layer
+  const int nchunk = (K + 31) >> 5;
+  BFrag<1> f1;
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 1 < nchunk) { if (KN) load_bfrag_kn(f1, Wn, N, K, c + 1, wave, c16, q); else load_bfrag<1>(f1, Wn, K, c + 1, wave, c16, q); }
+    mma_chunk<1, MT>(acc, f0, A, K, c, c16, q);
+    if (c + 1 < nchunk) {
+      if (c + 2 < nchunk) { if (KN) load_bfrag_kn(f0, Wn, N, K, c + 2, wave, c16, q); else load_bfrag<1>(f0, Wn, K, c + 2, wave, c16, q); }
+      mma_chunk<1, MT>(acc, f1, A, K, c + 1, c16, q);
+    }
+  }
+}
+
+__device__ __forceinline__ void preload_w_kn(BFrag<1> &f, const float *__restrict__ Wkn, int N, int K, int wave, int c16,
+                                             int q) {
+  if (wave < (N >> 4)) load_bfrag_kn(f, Wkn, N, K, 0, wave, c16, q);
+}
+
+// GEMM of a phase: acc[mt][0] (rows 16 mt.., N tile of this wave) += A[R x K] (LDS, row stride ACT_LD) * W.
+// M = 16..64 rows is the GEMV-like regime: every wave streams ITS OWN slice of W straight into VGPRs (no
+// LDS staging, no workgroup barrier in the K loop), two 32-deep chunks in flight.
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+#ifdef STDADK_DIAG   // diagnostic build only: in-kernel wall-clock stamps of the phases
+#define STAMP(i) do { if (a.stamps && tid == 0) a.stamps[tile * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+template <int MT>
+__device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem, float *red, const int tile) {
+  constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
+  float *act0 = smem, *act1 = smem + R * ACT_LD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
+  const int q = lane >> 4, c16 = lane & 15;
+  const int row0 = tile * R;
+  STAMP(0);
+  BFrag<1> wpre;
+  if (a.n_layers > 0) preload_w(wpre, a.L[0].W, a.L[0].h, a.L[0].hp, wave, c16, q);
+  {
+    // input tile: unconditional loads from clamped rows (rows >= B duplicate the last row; nothing
+    // computed for them is ever stored), 4 per thread in flight
+    const int v4 = a.h_in >> 2;            // <= 64 float4 per row => R*v4 <= 64*R
+    constexpr int NLD = 64 * R / TT;
+    float4 tv[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = min(tid + TT * i, R * v4 - 1);
+      const int row = idx / v4, c4 = idx - row * v4;
+      tv[i] = *reinterpret_cast<const float4 *>(a.a_in + (size_t)min(row0 + row, a.B - 1) * a.h_in + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + TT * i;
+      if (idx < R * v4) {
+        const int row = idx / v4, c4 = idx - row * v4;
+        *reinterpret_cast<float4 *>(act0 + row * ACT_LD + 4 * c4) = tv[i];
+      }
+    }
+  }
+  lds_barrier();
+  const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  float *cur = act0, *nxt = act1;
+  STAMP(1);
+  // output-layer weights of q = 0 (the MSE head has Q = 1): requested now, used at the very end
+  const int hl_head = a.n_layers ? a.L[a.n_layers - 1].h : a.h_in;
+  float wo0[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) wo0[cc] = a.Wo[min(lane + 64 * cc, hl_head - 1)];
+  const float bo0 = a.bo[0];
+
+  for (int li = 0; li < a.n_layers; ++li) {
+    const TailLayer &L = a.L[li];
+    const int h = L.h, hp = L.hp;
+    const int NT = h >> 4;
+    // LayerNorm parameters of this layer: requested before the GEMM, consumed after it (one L2 round
+    // trip hidden); clamped columns, no conditional loads
+    float gv[4], bev[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int colc = min(lane + 64 * cc, h - 1);
+      gv[cc] = a.layernorm ? L.g[colc] : 1.f;
+      bev[cc] = a.layernorm ? L.be[colc] : 0.f;
+    }
+    f32x4 acc[MT][MAX_NI];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre);
+    if (li + 1 < a.n_layers) preload_w(wpre, a.L[li + 1].W, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q);
+    STAMP(2 + 4 * li);
+    // z = acc + bias into the other activation buffer
+#pragma unroll
+    for (int i = 0; i < MAX_NI; ++i) {
+      const int t = wave + NW * i;
+      if (t < NT) {
+        const int col = 16 * t + c16;
+        const float bv = L.b[col];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nxt[(16 * mt + 4 * q + r) * ACT_LD + col] = acc[mt][i][r] + bv;
+      }
+    }
+    lds_barrier();
+    STAMP(3 + 4 * li);
+    // LayerNorm -> ReLU -> Dropout, wave w owns rows RPW*w .. RPW*w+RPW-1
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = RPW * wave + rr;
+      const int grow = row0 + row;
+      float z[4];
+      float s = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int col = lane + 64 * cc;
+        z[cc] = col < h ? nxt[row * ACT_LD + col] : 0.f;
+        s += z[cc];
+      }
+      float mean = 0.f, rs = 1.f;
+      if (a.layernorm) {
+        mean = wave_sum(s) / (float)h;
+        float sq = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float d = (lane + 64 * cc < h) ? z[cc] - mean : 0.f;
+          sq += d * d;
+        }
+        rs = 1.0f / sqrtf(wave_sum(sq) / (float)h + a.eps);
+        if (lane == 0 && grow < a.B) L.rstd[grow] = rs;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int col = lane + 64 * cc;
+        const float xh = a.layernorm ? (z[cc] - mean) * rs : z[cc];
+        const float u = fmaf(xh, gv[cc], bev[cc]);
+        float v = fmaxf(u, 0.f);
+        if (a.drop_p > 0.f) {
+          const bool keep = drop_keep(seed, L.layer_id, (int64_t)grow * h + col, a.drop_p);
+          v = keep ? v * keep_scale : 0.f;
+        }
+        if (col < h) {
+          nxt[row * ACT_LD + col] = v;
+          if (grow < a.B) {
+            L.xhat[(size_t)grow * h + col] = xh;
+            L.act[(size_t)grow * h + col] = v;
+          }
+        }
+      }
+    }
+    STAMP(4 + 4 * li);
+    lds_barrier();
+    STAMP(5 + 4 * li);
+    float *tmp = cur; cur = nxt; nxt = tmp;
+  }
+
+  // output layer (+ loss): y[row][qq] = a_last[row,:] . Wo[qq,:] + bo[qq]
+  const int hl = a.n_layers ? a.L[a.n_layers - 1].h : a.h_in;
+  float lsum = 0.f;
+  const bool plain_mse = a.loss.kind == STDADK_LOSS_MSE && a.loss.y_cols == a.Q;
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = RPW * wave + rr;
+    const int grow = row0 + row;
+    float mine = 0.f;              // lane q keeps prediction q of this row (general objectives)
+    for (int qq = 0; qq < a.Q; ++qq) {
+      float s = 0.f;
+      if (qq == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          if (lane + 64 * cc < hl) s = fmaf(cur[row * ACT_LD + lane + 64 * cc], wo0[cc], s);
+      } else {
+        for (int col = lane; col < hl; col += 64) s = fmaf(cur[row * ACT_LD + col], a.Wo[qq * hl + col], s);
+      }
+      s = wave_sum(s);
+      const float yv = s + (qq == 0 ? bo0 : a.bo[qq]);
+      mine = lane == qq ? yv : mine;
+      if (lane == 0 && grow < a.B) {
+        a.y_pred[(size_t)grow * a.Q + qq] = yv;
+        if (a.y && plain_mse) {
+          const float d = yv - a.y[(size_t)grow * a.Q + qq];
+          lsum = fmaf(d, d, lsum);
+          if (a.dY) a.dY[(size_t)grow * a.Q + qq] = 2.0f * d * a.grad_scale;
+        }
+      }
+    }
+    if (a.y && !plain_mse) {
+      // check loss / non-crossing / broadcast targets: lane q owns element (row, q)
+      const float yup = __shfl(mine, lane + 1, 64);
+      const float ydn = __shfl(mine, lane - 1, 64);
+      if (lane < a.Q && grow < a.B) {
+        const float yt = a.y[(size_t)grow * a.loss.y_cols + (a.loss.y_cols == 1 ? 0 : lane)];
+        float dy;
+        lsum += loss_elem(a.loss, a.Q, lane, loss_tau(a.loss, lane), mine, yup, ydn, yt, a.grad_scale, dy);
+        if (a.dY) a.dY[(size_t)grow * a.Q + lane] = dy;
+      }
+    }
+  }
+  STAMP(14);
+  if (a.y && a.loss_sum) {
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wave] = lsum;
+    lds_barrier();
+    if (tid == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w];
+      atomicAdd(a.loss_sum, t);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward (data path): dA / dZ of every hidden layer + column partials for dgamma, dbeta, db
+// ---------------------------------------------------------------------------------------------
+template <int MT>
+__device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem, const int tile) {
+  constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
+  float *d0 = smem, *d1 = smem + R * ACT_LD;
+  // column-partial scratch [3][NW][256]: with 64 rows the spare activation buffer is large enough and
+  // free during the LayerNorm phase, so it is aliased there instead of taking another 48 KiB
+  constexpr bool RED_ALIAS = (size_t)R * ACT_LD >= (size_t)3 * NW * 256;
+  float *red_own = smem + 2 * R * ACT_LD;
+  float *sdy = red_own + (RED_ALIAS ? 0 : 3 * NW * 256);   // [R][TAIL_MAXQ]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, c16 = lane & 15;
+  const int row0 = tile * R;
+  STAMP(0);
+  // Global inputs of a layer's LayerNorm-backward phase: all loads issued together from clamped
+  // addresses, unconditionally (one L2 round trip), and one phase EARLY — for the last layer right here
+  // (hidden behind the head phase),
+  // for layer li-1 just before the dA GEMM of pass li, so the round trip hides behind the MFMA work.
+  float gv[4], bev[4], xv[RPW][4], rsv[RPW];
+  auto ln_inputs = [&](const TailLayer &Ln) {
+    const int hn = Ln.h;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int colc = min(lane + 64 * cc, hn - 1);
+      gv[cc] = a.layernorm ? Ln.g[colc] : 1.f;
+      bev[cc] = a.layernorm ? Ln.be[colc] : 0.f;
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int growc = min(row0 + RPW * wave + rr, a.B - 1);
+        xv[rr][cc] = Ln.xhat[(size_t)growc * hn + colc];
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) rsv[rr] = a.layernorm ? Ln.rstd[min(row0 + RPW * wave + rr, a.B - 1)] : 1.f;
+  };
+  ln_inputs(a.L[a.n_layers - 1]);
+
+  if (tid < R * TAIL_MAXQ) {
+    const int row = tid / a.Q, qq = tid - row * a.Q;
+    sdy[tid] = (tid < R * a.Q && row0 + row < a.B) ? a.dY[(size_t)(row0 + row) * a.Q + qq] : 0.f;
+  }
+  lds_barrier();
+  const int hl = a.L[a.n_layers - 1].h;
+  for (int idx = tid; idx < R * hl; idx += TT) {
+    const int row = idx / hl, col = idx - row * hl;
+    float d = 0.f;
+    for (int qq = 0; qq < a.Q; ++qq) d = fmaf(sdy[row * a.Q + qq], a.Wo[qq * hl + col], d);
+    d0[row * ACT_LD + col] = d;
+  }
+  // output-layer weight gradient partials of this tile: part_head[blk][Q*hl (dWo) | Q (dbo)]
+  {
+    float *ph = a.part_head + (size_t)tile * a.Q * (hl + 1);
+    const int nrow = min(R, a.B - row0);
+    for (int col = tid; col < hl; col += TT) {
+      float pw[TAIL_MAXQ];
+#pragma unroll
+      for (int qq = 0; qq < TAIL_MAXQ; ++qq) pw[qq] = 0.f;
+      // 16 rows of the last activations in flight at a time (clamped rows: sdy is 0 beyond the batch)
+#pragma unroll
+      for (int rb = 0; rb < R; rb += 16) {
+        float av[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          av[r] = a.act_last[(size_t)min(row0 + rb + r, a.B - 1) * hl + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int qq = 0; qq < TAIL_MAXQ; ++qq)
+            if (qq < a.Q) pw[qq] = fmaf(sdy[(rb + r) * a.Q + qq], av[r], pw[qq]);
+      }
+#pragma unroll
+      for (int qq = 0; qq < TAIL_MAXQ; ++qq)
+        if (qq < a.Q) ph[qq * hl + col] = pw[qq];
+    }
+    if (tid < a.Q) {
+      float sb = 0.f;
+      for (int row = 0; row < nrow; ++row) sb += sdy[row * a.Q + tid];
+      ph[a.Q * hl + tid] = sb;
+    }
+  }
+  lds_barrier();
+  const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  float *cur = d0, *nxt = d1;
+  STAMP(1);                     // head phase done (dA of the last layer, dWo / dbo partials)
+
+  for (int li = a.n_layers - 1; li >= 0; --li) {
+    const TailLayer &L = a.L[li];
+    const int h = L.h;
+    BFrag<1> wpre;
+    if (li > 0) preload_w_kn(wpre, L.W, L.hp, h, wave, c16, q);       // for the dA GEMM at the end of this pass
+    // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows RPW*w .. of this wave.  Its global inputs
+    // (xhat rows, gamma, beta, rstd) were requested one phase early (ln_inputs below).
+    float pg[4], pb[4], pz[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) pg[cc] = pb[cc] = pz[cc] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = RPW * wave + rr;
+      const int grow = row0 + row;
+      const bool valid = grow < a.B;
+      float dxh[4];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int col = lane + 64 * cc;
+        const bool ok = valid && col < h;
+        const float x = xv[rr][cc];
+        const float u = fmaf(x, gv[cc], bev[cc]);
+        float d = cur[row * ACT_LD + min(col, TAIL_MAX_W - 1)];
+        if (a.drop_p > 0.f) {
+          const bool keep = drop_keep(seed, L.layer_id, (int64_t)grow * h + col, a.drop_p);
+          d = keep ? d * keep_scale : 0.f;
+        }
+        d = (ok && u > 0.f) ? d : 0.f;
+        if (a.layernorm) {
+          pg[cc] += d * x;
+          pb[cc] += d;
+          d *= gv[cc];
+          s1 += d;
+          s2 += d * x;
+        }
+        dxh[cc] = d;
+      }
+      float m1 = 0.f, m2 = 0.f;
+      if (a.layernorm) {
+        m1 = wave_sum(s1) / (float)h;
+        m2 = wave_sum(s2) / (float)h;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int col = lane + 64 * cc;
+        if (col < h) {
+          const float dz = (a.layernorm && valid) ? rsv[rr] * (dxh[cc] - m1 - xv[rr][cc] * m2) : dxh[cc];
+          cur[row * ACT_LD + col] = dz;
+          if (valid) a.dZ[li][(size_t)grow * h + col] = dz;
+          pz[cc] += dz;
+        }
+      }
+    }
+    // column partials of this workgroup's rows (`nxt` is not read again before the GEMM below refills it)
+    float *red = RED_ALIAS ? nxt : red_own;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      red[(0 * NW + wave) * 256 + lane + 64 * cc] = pg[cc];
+      red[(1 * NW + wave) * 256 + lane + 64 * cc] = pb[cc];
+      red[(2 * NW + wave) * 256 + lane + 64 * cc] = pz[cc];
+    }
+    lds_barrier();
+    if (tid < h) {
+      float *pbase = a.part[li] + (size_t)tile * 3 * h;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[(k * NW + w) * 256 + tid];
+        pbase[k * h + tid] = t;
+      }
+    }
+    STAMP(2 + 3 * (a.n_layers - 1 - li));      // LayerNorm-backward phase + column partials of this pass
+    if (li == 0) break;   // (the partials above are published by the barrier inside part (b) / kernel end)
+    // ---- (b) dA_prev[16 x hp] = dZ[16 x h] W[h x hp], with W^T ([hp][h], K contiguous) as the B operand
+    const int hp = L.hp;
+    const int NT = hp >> 4;
+    f32x4 acc[MT][MAX_NI];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ln_inputs(a.L[li - 1]);        // consumed after the GEMM, in the next pass
+    lds_barrier();                 // every wave's dZ rows are in `cur`
+    gemm16_pre<MT, true>(acc, cur, L.W, hp, h, wave, c16, q, wpre);
+    STAMP(3 + 3 * (a.n_layers - 1 - li));      // dA GEMM of this pass
+#pragma unroll
+    for (int i = 0; i < MAX_NI; ++i) {
+      const int t = wave + NW * i;
+      if (t < NT) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nxt[(16 * mt + 4 * q + r) * ACT_LD + 16 * t + c16] = acc[mt][i][r];
+      }
+    }
+    lds_barrier();
+    STAMP(4 + 3 * (a.n_layers - 1 - li));      // dA tile stored + barrier
+    float *tmp = cur; cur = nxt; nxt = tmp;
+  }
+}
+
+}  // namespace stdadk
