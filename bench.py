@@ -118,6 +118,10 @@ def kernel_work(name, B, D, H, P_flat, nnz_pairs, Kt, Q=1):
         return "hbm", 4.0 * P_flat, "B"
     if "rbf_build_kernel" in name:
         return "hbm", B * (12.0 + 4.0 * D), "B"
+    if "dw_all_kernel" in name:
+        # grouped dW_l = dZ_l^T a_{l-1} (l >= 1, + temporal rows of dW0^T) and the per-knot gather of dW0^T
+        fl = sum(2.0 * B * H[i] * H[i - 1] for i in range(1, len(H))) + 2.0 * B * Kt * H[0]
+        return "mfma", fl + 2.0 * nnz_pairs * H[0], "flop"
     if "l1_window_bwd_kernel" in name:
         return "mfma", 2.0 * nnz_pairs * H[0], "flop"    # dW0^T rows: one fma per non-zero (obs,knot) x H
     if "l1_window_fwd_kernel" in name:

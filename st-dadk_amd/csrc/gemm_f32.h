@@ -48,6 +48,7 @@ struct ReduceGroup {
   int first_block[REDUCE_GROUP_MAX + 1];
 };
 int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st);     // every job: a_km = b_km = true, aligned
+int gemm_tn_grouped_prepare(GemmGroup &grp, int *n_blocks);     // fills first_block; for launches that embed the group
 int launch_reduce_jobs(ReduceGroup &grp, hipStream_t st);
 bool gemm_tn_groupable(const float *A, int64_t lda, const float *B, int64_t ldb);
 

@@ -13,210 +13,9 @@
 // The MFMA sums k over the two lane halves (k = l>>5); a lane half h uses k = 8*s + 4*h + e for
 // MFMA e of sub-step s, for BOTH operands, so any k order is fine as long as A and B agree.
 #include "gemm_f32.h"
+#include "gemm_body.h"
 
 namespace stdadk {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;
-constexpr int GT = 256;  // threads
-
-template <int ROWS, bool KM>
-struct TileGeom {
-  static constexpr int STRIDE = KM ? ROWS : (BK + 4);
-  static constexpr int SIZE = KM ? BK * ROWS : ROWS * (BK + 4);
-  static constexpr int ELEMS = ROWS * BK / GT;  // floats per thread per stage
-};
-
-// Global -> registers for one operand tile.  `r0` first row (m or n) of the tile, `k0` first k.
-// VEC = contiguous floats per load along the operand's contiguous dimension.
-template <int ROWS, bool KM, int VEC>
-__device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t ld, int r0, int nrows,
-                                          int k0, int kend, float *reg) {
-  // Every load is UNCONDITIONAL from a clamped, always-valid address (the tile's first row / k when
-  // out of range) and masked in registers afterwards: a conditional load gets its own branch and a
-  // vmcnt(0), which would serialise the register-prefetch pipeline of the K loop.
-  const int tid = threadIdx.x;
-  constexpr int N_VEC = TileGeom<ROWS, KM>::ELEMS / VEC;
-  if (!KM) {
-    constexpr int VPR = BK / VEC;       // vectors per row
-    constexpr int RPP = GT / VPR;       // rows per pass
-#pragma unroll
-    for (int i = 0; i < N_VEC; ++i) {
-      const int row = tid / VPR + i * RPP;
-      const int k = k0 + (tid % VPR) * VEC;
-      const bool rok = (r0 + row) < nrows;
-      const bool ok = rok && k < kend;
-      const float *src = P + (int64_t)(rok ? r0 + row : r0) * ld + (k < kend ? k : k0);
-      if (VEC == 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(src);
-        reg[i * 4 + 0] = (ok && k + 0 < kend) ? v.x : 0.f;
-        reg[i * 4 + 1] = (ok && k + 1 < kend) ? v.y : 0.f;
-        reg[i * 4 + 2] = (ok && k + 2 < kend) ? v.z : 0.f;
-        reg[i * 4 + 3] = (ok && k + 3 < kend) ? v.w : 0.f;
-      } else if (VEC == 2) {
-        const float2 v = *reinterpret_cast<const float2 *>(src);
-        reg[i * 2 + 0] = (ok && k + 0 < kend) ? v.x : 0.f;
-        reg[i * 2 + 1] = (ok && k + 1 < kend) ? v.y : 0.f;
-      } else {
-        const float v = *src;
-        reg[i] = ok ? v : 0.f;
-      }
-    }
-  } else {
-    constexpr int VPR = ROWS / VEC;     // vectors per k-row
-    constexpr int KPP = GT / VPR;       // k-rows per pass
-#pragma unroll
-    for (int i = 0; i < N_VEC; ++i) {
-      const int kk = tid / VPR + i * KPP;
-      const int r = r0 + (tid % VPR) * VEC;
-      const bool kok = (k0 + kk) < kend;
-      const bool ok = kok && r < nrows;
-      const float *src = P + (int64_t)(kok ? k0 + kk : k0) * ld + (r < nrows ? r : r0);
-      if (VEC == 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(src);
-        reg[i * 4 + 0] = (ok && r + 0 < nrows) ? v.x : 0.f;
-        reg[i * 4 + 1] = (ok && r + 1 < nrows) ? v.y : 0.f;
-        reg[i * 4 + 2] = (ok && r + 2 < nrows) ? v.z : 0.f;
-        reg[i * 4 + 3] = (ok && r + 3 < nrows) ? v.w : 0.f;
-      } else if (VEC == 2) {
-        const float2 v = *reinterpret_cast<const float2 *>(src);
-        reg[i * 2 + 0] = (ok && r + 0 < nrows) ? v.x : 0.f;
-        reg[i * 2 + 1] = (ok && r + 1 < nrows) ? v.y : 0.f;
-      } else {
-        const float v = *src;
-        reg[i] = ok ? v : 0.f;
-      }
-    }
-  }
-}
-
-template <int ROWS, bool KM, int VEC>
-__device__ __forceinline__ void store_tile(float *lds, const float *reg) {
-  const int tid = threadIdx.x;
-  constexpr int N_VEC = TileGeom<ROWS, KM>::ELEMS / VEC;
-  constexpr int STRIDE = TileGeom<ROWS, KM>::STRIDE;
-  if (!KM) {
-    constexpr int VPR = BK / VEC;
-    constexpr int RPP = GT / VPR;
-#pragma unroll
-    for (int i = 0; i < N_VEC; ++i) {
-      int row = tid / VPR + i * RPP;
-      int k = (tid % VPR) * VEC;
-      float *dst = lds + row * STRIDE + k;
-      if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(reg[i * 4], reg[i * 4 + 1], reg[i * 4 + 2], reg[i * 4 + 3]);
-      else if (VEC == 2) *reinterpret_cast<float2 *>(dst) = make_float2(reg[i * 2], reg[i * 2 + 1]);
-      else *dst = reg[i];
-    }
-  } else {
-    constexpr int VPR = ROWS / VEC;
-    constexpr int KPP = GT / VPR;
-#pragma unroll
-    for (int i = 0; i < N_VEC; ++i) {
-      int kk = tid / VPR + i * KPP;
-      int r = (tid % VPR) * VEC;
-      float *dst = lds + kk * STRIDE + r;
-      if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(reg[i * 4], reg[i * 4 + 1], reg[i * 4 + 2], reg[i * 4 + 3]);
-      else if (VEC == 2) *reinterpret_cast<float2 *>(dst) = make_float2(reg[i * 2], reg[i * 2 + 1]);
-      else *dst = reg[i];
-    }
-  }
-}
-
-// fragment of sub-step s for the 32 rows starting at `row` of an LDS operand image
-template <int ROWS, bool KM>
-__device__ __forceinline__ void read_frag(const float *lds, int row, int s, int lane, float *f) {
-  constexpr int STRIDE = TileGeom<ROWS, KM>::STRIDE;
-  const int r = row + (lane & 31), h = lane >> 5;
-  if (!KM) {
-    float4 v = *reinterpret_cast<const float4 *>(lds + r * STRIDE + 8 * s + 4 * h);
-    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) f[e] = lds[(8 * s + 4 * h + e) * STRIDE + r];
-  }
-}
-
-template <int BM, int BN, bool A_KM, bool B_KM, int VA, int VB>
-__device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by, int bz, float *lds) {
-  constexpr int TM = BM / 64, TN = BN / 64;
-  using GA = TileGeom<BM, A_KM>;
-  using GB = TileGeom<BN, B_KM>;
-  float *As = lds, *Bs = lds + GA::SIZE;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = by * BM, n0 = bx * BN;
-  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-  int kbeg = 0, kend = g.K;
-  if (g.splits > 1) {
-    kbeg = bz * g.kps;
-    kend = min(g.K, kbeg + g.kps);
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float ra[GA::ELEMS], rb[GB::ELEMS];
-  if (kbeg < kend) {
-    load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
-    load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    store_tile<BM, A_KM, VA>(As, ra);
-    store_tile<BN, B_KM, VB>(Bs, rb);
-    __syncthreads();
-    if (k0 + BK < kend) {
-      load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, k0 + BK, kend, ra);
-      load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, k0 + BK, kend, rb);
-    }
-#pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      float fa[TM][4], fb[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) read_frag<BM, A_KM>(As, wm + i * 32, s, lane, fa[i]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) read_frag<BN, B_KM>(Bs, wn + j * 32, s, lane, fb[j]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  // epilogue: acc reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile
-  float *Cbase;
-  int64_t ldc;
-  if (g.splits > 1 || g.always_slab) {
-    Cbase = g.slab + (int64_t)bz * g.slab_stride;
-    ldc = g.N;
-  } else {
-    Cbase = g.C;
-    ldc = g.ldc;
-  }
-  const int h = lane >> 5, cl = lane & 31;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      int col = n0 + wn + j * 32 + cl;
-      if (col >= g.N) continue;
-      float bv = (g.splits == 1 && !g.always_slab && g.bias) ? g.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < g.M) Cbase[(int64_t)row * ldc + col] = acc[i][j][r] + bv;
-      }
-    }
-}
 
 template <int BM, int BN, bool A_KM, bool B_KM, int VA, int VB>
 __global__ __launch_bounds__(GT) void gemm_f32_kernel(GemmArgs g) {
@@ -228,14 +27,7 @@ __global__ __launch_bounds__(GT) void gemm_f32_kernel(GemmArgs g) {
 // (job, tile, split) through a prefix table; every job writes split-K slabs.
 __global__ __launch_bounds__(GT) void gemm_tn_grouped_kernel(GemmGroup grp) {
   __shared__ __attribute__((aligned(16))) float lds[TileGeom<64, true>::SIZE * 2];
-  int j = 0;
-  while (j + 1 < grp.n && (int)blockIdx.x >= grp.first_block[j + 1]) ++j;
-  const GemmArgs &g = grp.job[j];
-  int b = blockIdx.x - grp.first_block[j];
-  const int tn = (g.N + 63) >> 6, tm = (g.M + 63) >> 6;
-  const int bz = b / (tn * tm);
-  b -= bz * tn * tm;
-  gemm_tile_body<64, 64, true, true, 4, 4>(g, b % tn, b / tn, bz, lds);
+  gemm_tn_grouped_block(grp, (int)blockIdx.x, lds);
 }
 
 // dst_j[i] = sum_s src_j[s*stride_j + i], i < n_j, for a table of jobs, fixed summation order.
@@ -287,7 +79,7 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceGroup grp) {
   if (ty == 0 && c < jb.n) jb.dst[c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
-int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st) {
+int gemm_tn_grouped_prepare(GemmGroup &grp, int *n_blocks) {
   int nb = 0;
   for (int j = 0; j < grp.n; ++j) {
     GemmArgs &g = grp.job[j];
@@ -296,6 +88,14 @@ int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st) {
     grp.first_block[j] = nb;
     nb += (int)(ceil_div(g.M, 64) * ceil_div(g.N, 64)) * g.splits;
   }
+  *n_blocks = nb;
+  return 0;
+}
+
+int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st) {
+  int nb = 0;
+  int rc = gemm_tn_grouped_prepare(grp, &nb);
+  if (rc) return rc;
   if (nb == 0) return 0;
   STDADK_LAUNCH(gemm_tn_grouped_kernel, dim3((unsigned)nb), dim3(GT), 0, st, grp);
   STDADK_CHECK_LAUNCH("gemm_tn_grouped");

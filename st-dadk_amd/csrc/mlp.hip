@@ -483,6 +483,9 @@ struct Ctx {
   // with the backward chain as ONE kernel (the tail of a row tile is row-local through the loss)
   bool fuse_tail = false, pend_valid = false;
   TailFwdArgs pend;
+  bool merge_dw = false, dw_pend = false;   // window path: grouped dW products + per-knot gather as one launch
+  GemmGroup gg_pend;
+  ReduceGroup rg_pend;
   bool l1_pend_valid = false;   // window path, B <= 4096: the layer-0 launch is parked as well
   L1FwdArgs l1_pend;
   int l1_basis = 0;
@@ -734,6 +737,12 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
       if (rc) return rc;
     }
     c.n_extra = 0;     // consumed
+    if (c.merge_dw && !layer0_dense) {
+      // window path: the caller issues these products together with the per-knot gather of dW0^T as one
+      // launch, then the reductions (step_backward)
+      c.gg_pend = gg; c.rg_pend = rg; c.dw_pend = true;
+      return 0;
+    }
     rc = launch_gemm_tn_grouped(gg, st);
     if (rc) return rc;
     rc = launch_reduce_jobs(rg, st);
@@ -1031,7 +1040,7 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
 }
 
 // dW0^T spatial rows (window path): every knot row by the wave that owns it
-static int window_dw0(Ctx &c, hipStream_t st) {
+static int window_dw0(Ctx &c, hipStream_t st, GemmGroup *with_products = nullptr) {
   const stdadk_basis_desc *b = c.basis;
   float *ws = c.ws;
   L1BwdArgs a;
@@ -1046,6 +1055,7 @@ static int window_dw0(Ctx &c, hipStream_t st) {
     a.W0T = c.P->W[0];
     a.kpart = ws + c.pl.kpart;
   }
+  if (with_products) return launch_dw_all(*with_products, a, b->basis, st);
   return l1_window_backward(a, b->basis, st);
 }
 
@@ -1114,9 +1124,18 @@ static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const 
       return window_dw0(cc, cc.aux);
     };
   }
+  c.merge_dw = !c.aux && getenv("STDADK_NO_DW_ALL") == nullptr;
+  c.dw_pend = false;
   rc = run_backward(c, ws + c.pl.dY, nullptr, 0, false);
   c.fork_after_dz = nullptr;
+  c.merge_dw = false;
   if (rc) return rc;
+  if (c.dw_pend) {
+    c.dw_pend = false;
+    rc = window_dw0(c, c.st, &c.gg_pend);
+    if (rc) return rc;
+    return launch_reduce_jobs(c.rg_pend, c.st);
+  }
   for (int e = 0; e < c.n_extra; ++e) {     // not consumed by a grouped launch
     rc = gemm_run(c.extra[e].A, c.extra[e].lda, true, c.dz0, H, true, c.extra[e].M, H, (int)c.B, nullptr,
                   c.extra[e].C, H, ws + c.pl.slab, false, nullptr, c.st);

@@ -87,6 +87,12 @@ int knot_halo(const GridView &g, int *halo, hipStream_t st);
 // wave: no atomics, summation in sorted-observation order => bitwise reproducible).
 int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st);
 
+}  // namespace stdadk
+#include "gemm_f32.h"
+namespace stdadk {
+// the grouped dW products of the other layers and this per-knot gather as ONE launch (dw_all.hip)
+int launch_dw_all(GemmGroup &grp, const L1BwdArgs &a, int basis, hipStream_t st);
+
 // out[perm[i]*Q + q] = in[i*Q + q]
 int unpermute_rows(const float *in, const int *perm, int B, int Q, float *out, hipStream_t st);
 
