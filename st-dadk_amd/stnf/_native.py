@@ -38,6 +38,7 @@ class BasisDesc(C.Structure):
                 ("t_bw", C.c_void_p)]
 
 
+ABI_VERSION = 3            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
 MAX_Q = 8
 LOSS_MSE, LOSS_PINBALL = 0, 1
 
@@ -151,7 +152,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError => the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.stdadk_abi_version() != 3:
+        if handle.stdadk_abi_version() != ABI_VERSION:
             raise NativeLibraryError("libstdadk.so ABI version mismatch")
         _lib = handle
     return _lib

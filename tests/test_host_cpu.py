@@ -289,3 +289,13 @@ def test_data_adaptive_initialisers_match_reference():
         SpatialBasisEmbedding(n_centers=[9], init_method="gmm")
     with pytest.raises(ValueError):
         SpatialBasisEmbedding(n_centers=[9], init_method="bogus")
+
+
+def test_graft_entry_build_imports_and_checks_abi():
+    """__graft_entry__.build() (what the driver runs on CPU): compiles, imports the package and agrees
+    with the header's ABI version."""
+    import __graft_entry__ as g
+    from stnf import _native as N
+    g.build()
+    hdr = open(os.path.join(ROOT, "include", "stdadk.h")).read()
+    assert int(re.search(r"#define STDADK_ABI_VERSION (\d+)", hdr).group(1)) == N.ABI_VERSION
