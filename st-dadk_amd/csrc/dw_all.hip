@@ -14,6 +14,7 @@ static_assert(GT == BW_T, "the GEMM tiles and the knot groups must share the wor
 template <int CPL, int BASIS, bool KNOTS>
 __global__ __launch_bounds__(GT) void dw_all_kernel(GemmGroup grp, int n_gemm_blocks, L1BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[TileGeom<64, true>::SIZE * 2];
+  // GEMM tiles take the low block ids (dispatched first): measured 33.5 us vs 42.5 us the other way round
   if ((int)blockIdx.x < n_gemm_blocks) gemm_tn_grouped_block(grp, (int)blockIdx.x, lds);
   else l1_window_bwd_body<CPL, BASIS, KNOTS>(a, (int)blockIdx.x - n_gemm_blocks);
 }
