@@ -19,11 +19,20 @@ __global__ __launch_bounds__(TT) void l1_tail_kernel(L1FwdArgs l, TailFwdArgs f,
   const int tile = l1_chunk_of(blockIdx.x, l.n_wg);          // XCD-aware tile order (l.rows_per_wg == 16)
   const int r0 = 16 * tile;
   if (r0 >= l.B) return;                                      // padding workgroup (grid is a multiple of 8)
+#ifdef STDADK_DIAG   // diagnostic build: phase boundaries into slots 10..13 of the forward stamp buffer
+#define PSTAMP(i) do { if (f.stamps && threadIdx.x == 0) f.stamps[tile * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+  PSTAMP(10);
   l1_window_fwd_body<CPL, LN, BASIS, FREE>(l, smem, r0, min(r0 + 16, l.B));
+  PSTAMP(11);
   __syncthreads();
   tail_fwd_body<1>(f, smem, red, tile);
+  PSTAMP(12);
   __syncthreads();
   tail_bwd_body<1>(b, smem, tile);
+  PSTAMP(13);
 }
 
 template <int CPL, bool LN, int BASIS, bool FREE>

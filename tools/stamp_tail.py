@@ -39,3 +39,14 @@ for name, s, labels in (("tail_fwd", sf, ["input", "gemm1", "z->lds+bar", "ln1",
         prev = c; li += 1
     tot = (st[:, cols[-1]] - st[:, cols[0]]) / 100.0
     print(f"  total in-kernel median {tot.median().item():.2f} us")
+
+# fused step kernel (B <= 4096): phase boundaries in slots 10..13 of the forward stamp buffer
+st = sf.view(-1, 16).cpu().double()
+st = st[(st[:, 10] > 0)]
+if st.shape[0]:
+    for a, b, lab in ((10, 11, "layer-0 window phase"), (11, 12, "sync + tail forward"), (12, 13, "sync + tail backward")):
+        d = (st[:, b] - st[:, a]) / 100.0
+        print(f"  fused {lab:24s} median {d.median().item():6.2f} us  max {d.max().item():6.2f}")
+    tot = (st[:, 13] - st[:, 10]) / 100.0
+    print(f"  fused total in-kernel median {tot.median().item():.2f} us  max {tot.max().item():.2f}")
+    print(f"  first workgroup start -> last workgroup end: {(st[:, 13].max() - st[:, 10].min()).item() / 100.0:.2f} us")
