@@ -1316,3 +1316,55 @@ def test_run_epoch_equals_manual_loop():
         res.append((eng.flat.clone(), loss))
     assert torch.equal(res[0][0], res[1][0])
     assert abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[0][1])
+
+
+@pytest.mark.parametrize("variant", ["four_levels", "h128_noln", "tri_covariates", "learnable_tri", "q3_pinball",
+                                     "b4096", "b33"])
+def test_fused_step_kernels_window_vs_materialised(variant):
+    """The one-launch step kernels (layer 0 + tail forward/backward; all weight gradients) across their
+    template variants — level chunking, H = 128, no LayerNorm, triangular basis, covariates, learnable
+    knots, several outputs, a full 4096-row batch, a ragged 33-row one: two engine steps on the window
+    path against the same two steps on the materialising kernels."""
+    from stnf.models import STInterpMLP
+    from stnf.engine import TrainStep
+    d = dev()
+    kw = dict(p=0, k_spatial_centers=[1024, 1600], k_temporal_centers=[10, 15], hidden_dims=[256, 128],
+              dropout=0.0, layernorm=True, spatial_basis_function="wendland")
+    ekw, B, ycols = {}, 700, 1
+    if variant == "four_levels":
+        kw.update(k_spatial_centers=[64, 256, 576, 1600])
+    elif variant == "h128_noln":
+        kw.update(hidden_dims=[128, 64], layernorm=False)
+    elif variant == "tri_covariates":
+        kw.update(p=3, spatial_basis_function="triangular")
+    elif variant == "learnable_tri":
+        kw.update(spatial_learnable=True, spatial_basis_function="triangular", gradient_damping=True)
+        ekw.update(domain_penalty_weight=0.05, movement_penalty_weight=0.02)
+    elif variant == "q3_pinball":
+        kw.update(output_dim=3)
+        ekw.update(loss="pinball", quantile_levels=[0.1, 0.5, 0.9], non_crossing_weight=0.3)
+    elif variant == "b4096":
+        B = 4096
+    elif variant == "b33":
+        B = 33
+    rs = np.random.RandomState(sum(map(ord, variant)))       # deterministic per variant
+    coords = torch.from_numpy(rs.uniform(-0.02, 1.02, (B, 2)).astype(np.float32)).to(d)
+    t = torch.from_numpy(rs.uniform(0, 1, (B,)).astype(np.float32)).to(d)
+    y = torch.from_numpy(rs.standard_normal((B, ycols)).astype(np.float32)).to(d)
+    X = torch.from_numpy(rs.standard_normal((B, kw["p"])).astype(np.float32)).to(d) if kw["p"] else None
+    res = []
+    for dense in (False, True):
+        torch.manual_seed(4)
+        m = STInterpMLP(**kw).to(d)
+        if kw.get("spatial_learnable"):
+            with torch.no_grad():
+                m.spatial_basis.centers.add_(0.004 * torch.randn_like(m.spatial_basis.centers))
+        m.train()
+        eng = TrainStep(m, lr=1e-3, grad_clip=10.0, ema_decay=0.99, max_batch=B, force_dense=dense, **ekw)
+        assert eng.uses_window == (not dense)
+        for _ in range(2):
+            eng.step(X, coords, t, y)
+        res.append((eng.flat.clone().cpu().numpy(), eng.mean_loss()))
+    assert abs(res[0][1] - res[1][1]) <= 2e-5 * max(1.0, abs(res[1][1])), (res[0][1], res[1][1])
+    err = rel_l2(res[0][0], res[1][0])
+    assert err <= 5e-5, err
