@@ -89,13 +89,22 @@ class _LightEvent:
 
 
 class TrainStep:
-    """One fused optimisation step of STInterpMLP (fixed knots).
+    """One fused optimisation step of STInterpMLP (fixed or learnable knots).
 
     Objective (scripts/train_st_interp.py:617-658): loss="mse" (regression_type 'mean'), or
     loss="pinball" with `quantile_levels` — one level = 'quantile', several = 'multi-quantile' (mean
     over levels of the per-level check loss on (B,1) targets) plus either the prediction-level
     non-crossing penalty (non_crossing_weight, non_crossing_power) or, with the delta head, the
-    parameter-level P_nc(delta) (non_crossing_lambda)."""
+    parameter-level P_nc(delta) (non_crossing_lambda).
+
+    Learnable knots (`spatial_learnable=True` models; scripts/train_st_interp.py:470-499,660-672,698-705):
+    the knot tensors form their own AdamW group with lr x `basis_lr_ratio` (`set_basis_lr` for the
+    progressive unfreezing of :582-602) and clip norm `grad_clip` x `basis_clip_ratio`;
+    `domain_penalty_weight` / `movement_penalty_weight` add the penalties of st_interp.py:493-546 to the
+    objective, and the model's gradient-damping settings apply to the centres' gradient.
+
+    Launch mode: an eager chain of kernels by default (`use_graph=True` replays it from a hipGraph);
+    `step_indexed(..., next_idx=...)` / `run_epoch` overlap the next batch's preparation with the step."""
 
     def __init__(self, model, lr=2e-2, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
                  grad_clip=10.0, ema_decay=None, max_batch=4096, use_graph=False,
