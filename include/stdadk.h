@@ -187,6 +187,28 @@ int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *em
                          const float *sumsq_parts, int32_t n_parts, float grad_mul, float ema_decay,
                          stdadk_stream_t stream);
 
+/* A9 with two parameter groups in one launch each (learnable knots: the MLP parameters and the knot
+ * tensors are clipped on their own norms and stepped with their own learning rates,
+ * scripts/train_st_interp.py:470-483,698-705): stdadk_sumsq2_f32 = stdadk_sumsq_f32 on two buffers
+ * (step_inc advanced once), stdadk_adamw_ema2_f32 = stdadk_adamw_ema_f32 on two groups. */
+typedef struct stdadk_adam_group {
+  float *p;                   /* parameters, gradients, Adam moments, EMA shadow (NULL = no EMA) */
+  const float *g;
+  float *m, *v, *ema;
+  int64_t n;
+  float lr;                   /* used when lr_dev is NULL                                        */
+  const float *lr_dev;
+  float max_norm;             /* <= 0: no clipping                                               */
+  const float *sumsq_parts;   /* partial sums of squares of g (stdadk_sumsq*_f32)                */
+  int32_t n_parts;
+} stdadk_adam_group;
+int stdadk_sumsq2_f32(const float *g0, int64_t n0, float *parts0, const float *g1, int64_t n1,
+                      float *parts1, int32_t *step_inc, stdadk_stream_t stream);
+int stdadk_adamw_ema2_f32(const stdadk_adam_group *g0, const stdadk_adam_group *g1, float beta1,
+                          float beta2, float eps, float weight_decay, int32_t step,
+                          const int32_t *step_dev, float grad_mul, float ema_decay,
+                          stdadk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Step-level entry points: observations in, predictions / gradients out.
  *

@@ -912,10 +912,8 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
   if (c.log_bw) {
     // learnable knots: bandwidth = exp(log_bandwidth) (st_interp.py:146-148), and the candidate
     // windows follow wherever the knots are now
-    rc = launch_exp(b->s_bw, b->Ks, c.ws + pl.bw_exp, c.st);
-    if (rc) return rc;
     a.g.bw = c.ws + pl.bw_exp;
-    rc = knot_halo(a.g, (int *)(c.ws + pl.halo), c.st);
+    rc = knot_halo(a.g, (int *)(c.ws + pl.halo), c.st, b->s_bw, c.ws + pl.bw_exp);   // also fills bw_exp
     if (rc) return rc;
     a.halo = (const int *)(c.ws + pl.halo);
   }

@@ -8,12 +8,12 @@ namespace stdadk {
 // parts[blockIdx.x] = sum of squares of this block's slice (every one of the SUMSQ_PARTS entries is
 // written, so the buffer needs no zeroing and the sum order is fixed).
 constexpr int SUMSQ_PARTS = STDADK_SUMSQ_PARTS;
-__global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ g, int64_t n,
-                                                    float *__restrict__ parts, int *__restrict__ step_inc) {
-  if (step_inc && blockIdx.x == 0 && threadIdx.x == 0) step_inc[0] += 1;   // nobody else touches it here
+__device__ __forceinline__ void sumsq_block(const float *__restrict__ g, int64_t n, float *__restrict__ parts,
+                                            int *__restrict__ step_inc, const int block) {
+  if (step_inc && block == 0 && threadIdx.x == 0) step_inc[0] += 1;   // nobody else touches it here
   float acc = 0.f;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)SUMSQ_PARTS * blockDim.x;
+  int64_t i = (int64_t)block * blockDim.x + threadIdx.x;
   const int64_t n4 = n / 4;
   if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
     const float4 *g4 = reinterpret_cast<const float4 *>(g);
@@ -30,7 +30,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ g,
   float s = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) parts[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) parts[block] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ g, int64_t n,
+                                                    float *__restrict__ parts, int *__restrict__ step_inc) {
+  sumsq_block(g, n, parts, step_inc, (int)blockIdx.x);
+}
+
+// the clip norms of two parameter groups (MLP / learnable knots) in one launch: blocks [0, PARTS) take
+// group 0 (and advance the step counter), blocks [PARTS, 2 PARTS) group 1
+__global__ __launch_bounds__(256) void sumsq2_kernel(const float *__restrict__ g0, int64_t n0, float *__restrict__ parts0,
+                                                     const float *__restrict__ g1, int64_t n1, float *__restrict__ parts1,
+                                                     int *__restrict__ step_inc) {
+  if ((int)blockIdx.x < SUMSQ_PARTS) sumsq_block(g0, n0, parts0, step_inc, (int)blockIdx.x);
+  else sumsq_block(g1, n1, parts1, nullptr, (int)blockIdx.x - SUMSQ_PARTS);
 }
 
 struct AdamArgs {
@@ -54,12 +68,12 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
   if (ema) *ema = fmaf(ema_decay, *ema, (1.f - ema_decay) * p);
 }
 
-__global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
+__device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int block, const int nblocks) {
   // The first (for up to 4 M parameters: the only) float4 group of every stream is requested BEFORE the
   // prologue below (partials of the clip norm, bias corrections), whose latency then hides behind it.
   typedef float nt4 __attribute__((ext_vector_type(4)));
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)nblocks * blockDim.x;
+  const int64_t i0 = (int64_t)block * blockDim.x + threadIdx.x;
   const bool al = ((reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(a.g) |
                     reinterpret_cast<uintptr_t>(a.m) | reinterpret_cast<uintptr_t>(a.v) |
                     reinterpret_cast<uintptr_t>(a.ema)) & 15) == 0;
@@ -131,6 +145,17 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
+  adamw_ema_block(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// two parameter groups (own lr, clip norm and clip partials each) in one launch: blocks [0, nb0) update
+// group 0, the rest group 1
+__global__ __launch_bounds__(256) void adamw_ema2_kernel(AdamArgs a0, AdamArgs a1, int nb0) {
+  if ((int)blockIdx.x < nb0) adamw_ema_block(a0, (int)blockIdx.x, nb0);
+  else adamw_ema_block(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+}
+
 __global__ void step_advance_kernel(int *s) { s[0] += 1; }
 
 }  // namespace stdadk
@@ -141,6 +166,16 @@ extern "C" int stdadk_step_advance(int32_t *step_dev, stdadk_stream_t stream) {
   STDADK_REQUIRE(step_dev, STDADK_E_ARG, "step_advance: NULL pointer");
   STDADK_LAUNCH(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
   STDADK_CHECK_LAUNCH("step_advance");
+  return 0;
+}
+
+extern "C" int stdadk_sumsq2_f32(const float *g0, int64_t n0, float *parts0, const float *g1, int64_t n1,
+                                 float *parts1, int32_t *step_inc, stdadk_stream_t stream) {
+  STDADK_REQUIRE(n0 >= 0 && n1 >= 0, STDADK_E_ARG, "sumsq2: negative n");
+  STDADK_REQUIRE(parts0 && parts1 && (g0 || n0 == 0) && (g1 || n1 == 0), STDADK_E_ARG, "sumsq2: NULL pointer");
+  STDADK_LAUNCH(sumsq2_kernel, dim3(2 * SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, g0, n0, parts0, g1, n1,
+                parts1, step_inc);
+  STDADK_CHECK_LAUNCH("sumsq2");
   return 0;
 }
 
@@ -171,5 +206,35 @@ extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v
   if (blocks > 4096) blocks = 4096;
   STDADK_LAUNCH(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   STDADK_CHECK_LAUNCH("adamw_ema");
+  return 0;
+}
+
+static int fill_group(AdamArgs &a, const stdadk_adam_group *gr, float beta1, float beta2, float eps, float wd,
+                      int32_t step, const int32_t *step_dev, float grad_mul, float ema_decay) {
+  STDADK_REQUIRE(gr && gr->n > 0 && gr->p && gr->g && gr->m && gr->v, STDADK_E_ARG, "adamw2: NULL pointer or empty group");
+  STDADK_REQUIRE(gr->max_norm <= 0.f || (gr->sumsq_parts && gr->n_parts > 0), STDADK_E_ARG,
+                 "adamw2: max_norm > 0 needs sumsq parts");
+  a.p = gr->p; a.g = gr->g; a.m = gr->m; a.v = gr->v; a.ema = gr->ema; a.n = gr->n; a.lr = gr->lr; a.lr_dev = gr->lr_dev;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.step = step; a.step_dev = step_dev;
+  a.max_norm = gr->max_norm; a.sumsq = gr->sumsq_parts; a.n_parts = gr->n_parts; a.grad_mul = grad_mul;
+  a.ema_decay = ema_decay;
+  return 0;
+}
+
+extern "C" int stdadk_adamw_ema2_f32(const stdadk_adam_group *g0, const stdadk_adam_group *g1, float beta1,
+                                     float beta2, float eps, float weight_decay, int32_t step,
+                                     const int32_t *step_dev, float grad_mul, float ema_decay,
+                                     stdadk_stream_t stream) {
+  STDADK_REQUIRE(step_dev || step >= 1, STDADK_E_ARG, "adamw2: step must be >= 1");
+  AdamArgs a0, a1;
+  int rc = fill_group(a0, g0, beta1, beta2, eps, weight_decay, step, step_dev, grad_mul, ema_decay);
+  if (rc) return rc;
+  rc = fill_group(a1, g1, beta1, beta2, eps, weight_decay, step, step_dev, grad_mul, ema_decay);
+  if (rc) return rc;
+  int64_t nb0 = ceil_div(a0.n, 256 * 4), nb1 = ceil_div(a1.n, 256 * 4);
+  if (nb0 > 4096) nb0 = 4096;
+  if (nb1 > 4096) nb1 = 4096;
+  STDADK_LAUNCH(adamw_ema2_kernel, dim3((unsigned)(nb0 + nb1)), dim3(256), 0, (hipStream_t)stream, a0, a1, (int)nb0);
+  STDADK_CHECK_LAUNCH("adamw_ema2");
   return 0;
 }

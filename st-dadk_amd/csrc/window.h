@@ -81,7 +81,8 @@ struct L1BwdArgs {
 // Per level: R = ceil(max_k (s_k + |c_k - grid_k|_inf) * (side-1)), the half-width (in grid cells) of the
 // candidate window that is guaranteed to contain every knot whose support reaches an observation,
 // wherever the learnable knots have moved and however their bandwidths have changed.
-int knot_halo(const GridView &g, int *halo, hipStream_t st);
+// With log_bw the bandwidths are taken as exp(log_bw) and also written to bw_out (one launch for both).
+int knot_halo(const GridView &g, int *halo, hipStream_t st, const float *log_bw = nullptr, float *bw_out = nullptr);
 
 // dW0T[p + k, :] = sum_b phi[b,k] dZ[b,:] for every spatial knot k (each knot row owned by one
 // wave: no atomics, summation in sorted-observation order => bitwise reproducible).

@@ -327,7 +327,10 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
 }
 
 // one workgroup per level: R = ceil(max_k (s_k + |c_k - grid_k|_inf) (side-1) + eps), clamped to [1, side]
-__global__ __launch_bounds__(256) void knot_halo_kernel(GridView g, int *__restrict__ halo) {
+// log_bw (optional): the bandwidths are given as logs; the kernel then also writes exp(log_bw) to bw_out
+// (the table the window kernels read), saving the separate exp launch
+__global__ __launch_bounds__(256) void knot_halo_kernel(GridView g, int *__restrict__ halo,
+                                                        const float *__restrict__ log_bw, float *__restrict__ bw_out) {
   const int l = blockIdx.x;
   const int side = g.side[l], off = g.off[l];
   const float sm1 = (float)(side > 1 ? side - 1 : 1);
@@ -337,7 +340,9 @@ __global__ __launch_bounds__(256) void knot_halo_kernel(GridView g, int *__restr
     const int ix = j / side, iy = j - ix * side;
     const float gx = side > 1 ? (float)ix / sm1 : 0.f, gy = side > 1 ? (float)iy / sm1 : 0.f;
     const float mv = fmaxf(fabsf(g.centers[2 * k] - gx), fabsf(g.centers[2 * k + 1] - gy));
-    const float v = (g.bw[k] * g.cal + mv) * sm1;
+    float bwk;
+    if (log_bw) { bwk = expf(log_bw[k]); bw_out[k] = bwk; } else { bwk = g.bw[k]; }
+    const float v = (bwk * g.cal + mv) * sm1;
     m = fmaxf(m, (v == v) ? v : 3.0e38f);          // NaN knots widen the window to the whole level
   }
 #pragma unroll
@@ -352,8 +357,9 @@ __global__ __launch_bounds__(256) void knot_halo_kernel(GridView g, int *__restr
   }
 }
 
-int knot_halo(const GridView &g, int *halo, hipStream_t st) {
-  STDADK_LAUNCH(knot_halo_kernel, dim3((unsigned)g.n_levels), dim3(256), 0, st, g, halo);
+int knot_halo(const GridView &g, int *halo, hipStream_t st, const float *log_bw, float *bw_out) {
+  STDADK_REQUIRE(!log_bw || bw_out, STDADK_E_ARG, "knot_halo: log_bw needs bw_out");
+  STDADK_LAUNCH(knot_halo_kernel, dim3((unsigned)g.n_levels), dim3(256), 0, st, g, halo, log_bw, bw_out);
   STDADK_CHECK_LAUNCH("knot_halo");
   return 0;
 }

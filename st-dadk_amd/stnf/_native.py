@@ -48,6 +48,12 @@ class LossDesc(C.Structure):
                 ("nc_weight", C.c_float), ("nc_power", C.c_int32)]
 
 
+class AdamGroup(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("lr_dev", C.c_void_p), ("max_norm", C.c_float),
+                ("sumsq_parts", C.c_void_p), ("n_parts", C.c_int32)]
+
+
 class KnotTrain(C.Structure):
     _fields_ = [("centers_init", C.c_void_p), ("gradient_damping", C.c_int32),
                 ("damping_threshold", C.c_float), ("damping_strength", C.c_float),
@@ -87,6 +93,11 @@ _SIGNATURES = {
     "stdadk_delta_head_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                  C.c_int32, C.c_int32, C.c_float, C.c_float,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stdadk_sumsq2_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "stdadk_adamw_ema2_f32": (C.c_int, [C.POINTER(AdamGroup), C.POINTER(AdamGroup), C.c_float, C.c_float,
+                                        C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float, C.c_float,
+                                        C.c_void_p]),
     "stdadk_step_uses_window": (C.c_int32, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.c_int32]),
     "stdadk_step_workspace_bytes": (C.c_size_t, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.c_int64,
                                                  C.c_int32]),
@@ -525,6 +536,33 @@ def adamw_ema(p, g, m, v, ema, lr, betas, eps, weight_decay, step, max_norm=0.0,
                                     0 if sumsq_parts is None else sumsq_parts.numel(),
                                     grad_mul, ema_decay, _stream())
     _check(rc, "stdadk_adamw_ema_f32")
+
+
+def sumsq2(g0, parts0, g1, parts1, step_inc=None):
+    """stdadk_sumsq_f32 on two gradient buffers in one launch (step_inc advanced once)."""
+    if parts0.numel() != SUMSQ_PARTS or parts1.numel() != SUMSQ_PARTS:
+        raise RuntimeError(f"sumsq2: parts must hold {SUMSQ_PARTS} floats each")
+    rc = lib().stdadk_sumsq2_f32(_dev(g0, "g0"), g0.numel(), _dev(parts0, "parts0"), _dev(g1, "g1"), g1.numel(),
+                                 _dev(parts1, "parts1"), _dev(step_inc, "step_inc"), _stream())
+    _check(rc, "stdadk_sumsq2_f32")
+
+
+def make_adam_group(p, g, m, v, ema, lr, lr_dev=None, max_norm=0.0, sumsq_parts=None):
+    gr = AdamGroup()
+    gr.p, gr.g, gr.m, gr.v, gr.ema = _dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), _dev(ema, "ema")
+    gr.n = p.numel()
+    gr.lr, gr.lr_dev = float(lr), _dev(lr_dev, "lr_dev")
+    gr.max_norm = float(max_norm)
+    gr.sumsq_parts = _dev(sumsq_parts, "sumsq")
+    gr.n_parts = 0 if sumsq_parts is None else sumsq_parts.numel()
+    return gr
+
+
+def adamw_ema2(group0, group1, betas, eps, weight_decay, step, grad_mul=1.0, ema_decay=0.0, step_dev=None):
+    """stdadk_adamw_ema_f32 on two parameter groups (make_adam_group) in one launch."""
+    rc = lib().stdadk_adamw_ema2_f32(C.byref(group0), C.byref(group1), betas[0], betas[1], eps, weight_decay,
+                                     int(step), _dev(step_dev, "step_dev"), grad_mul, ema_decay, _stream())
+    _check(rc, "stdadk_adamw_ema2_f32")
 
 
 def profile_enable(on=True):

@@ -264,6 +264,19 @@ class TrainStep:
         if self.distributed:
             D.allreduce_gradients(self.grad, self.pg)
         ke = self.knot_end
+        if ke and self.grad_clip > 0:
+            # learnable knots: both groups' clip norms in one launch, both AdamW/EMA updates in one launch
+            N.sumsq2(self.grad[ke:], self.sumsq, self.grad[:ke], self.sumsq_basis, step_inc=self.step_dev)
+            ema = self.ema
+            g_mlp = N.make_adam_group(self.flat[ke:], self.grad[ke:], self.m[ke:], self.v[ke:],
+                                      ema[ke:] if ema is not None else None, self.lr, self.lr_dev, self.grad_clip,
+                                      self.sumsq)
+            g_knot = N.make_adam_group(self.flat[:ke], self.grad[:ke], self.m[:ke], self.v[:ke],
+                                       ema[:ke] if ema is not None else None, self.basis_lr, self.basis_lr_dev,
+                                       self.basis_clip, self.sumsq_basis)
+            N.adamw_ema2(g_mlp, g_knot, self.betas, self.eps, self.wd, self.step_count + 1,
+                         ema_decay=self.ema_decay, step_dev=self.step_dev)
+            return
         if self.grad_clip > 0:
             N.sumsq(self.grad[ke:], self.sumsq, step_inc=self.step_dev)
             if ke:

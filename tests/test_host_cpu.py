@@ -237,6 +237,10 @@ def test_n3_host_surface():
     from stnf.models import STInterpMLP
     # stdadk_loss_desc: int32 kind, y_cols; float tau[8], nc_weight; int32 nc_power
     assert ctypes.sizeof(N.LossDesc) == 4 * (2 + 8 + 2)
+    # stdadk_adam_group: 5 pointers, int64 n, float lr (+pad), pointer, float max_norm (+pad), pointer, int32 (+pad)
+    assert ctypes.sizeof(N.AdamGroup) == 88 and N.AdamGroup.lr_dev.offset == 56 and N.AdamGroup.n_parts.offset == 80
+    # stdadk_knot_train: pointer, int32, 6 floats (+pad to 8)
+    assert ctypes.sizeof(N.KnotTrain) == 40
     ld = N.make_loss("pinball", 3, 1, [0.1, 0.5, 0.9], 0.5, 2)
     assert (ld.kind, ld.y_cols, ld.nc_power) == (1, 1, 2) and abs(ld.tau[2] - 0.9) < 1e-7
     with pytest.raises(ValueError, match="quantile levels"):
