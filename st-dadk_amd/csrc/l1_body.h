@@ -6,6 +6,16 @@
 
 namespace stdadk {
 
+// half-width R (grid cells) of the candidate window of a level from knot_halo()'s partial maxima:
+// ceil(max + eps), clamped to [1, side]
+__device__ __forceinline__ int halo_half_width(const float *__restrict__ halo, int l, int side) {
+  float m = 0.f;
+#pragma unroll
+  for (int s = 0; s < HALO_SPLIT; ++s) m = fmaxf(m, halo[l * HALO_SPLIT + s]);
+  const float r = ceilf(m + 1e-3f);
+  return r >= (float)side ? side : (r < 1.f ? 1 : (int)r);
+}
+
 // XCD-aware chunking: workgroups w and w+8 share an XCD (round-robin dispatch), so XCD x walks the
 // x-th contiguous eighth of the sorted observations and its L2 holds that eighth's W0^T rows.
 __device__ __forceinline__ int l1_chunk_of(int w, int n_wg) {
@@ -108,7 +118,7 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
       for (int l = l0; FREE && l < l1; ++l) {
         const int side = a.g.side[l];
         {
-          const int R = a.halo[l];
+          const int R = halo_half_width(a.halo, l, side);
           const int win = min(2 * R, side);
           const int hi = side - win;
           const int fx = floor_clamp(x * (float)(side - 1), side), fy = floor_clamp(y * (float)(side - 1), side);

@@ -43,7 +43,7 @@ struct Plan {
   // step-level buffers
   size_t feats; int64_t ldf;           // dense: materialised features
   size_t bw_exp, kpart; int kslabs;    // learnable knots: exp(log_bw) [Ks], per-slab knot partials
-  size_t halo;                         // learnable knots, window path: per-level candidate half-widths (ints)
+  size_t halo;                         // learnable knots, window path: per-level partial maxima of the candidate reach
   size_t psi; int ld_psi;              // window: temporal basis [B][ld_psi]
   size_t ypred, dY;                    // [B*Q]
   size_t keys, hist, cursor, cell_start, perm_tmp, perm, xs, ys, ts, y_s, X_s;
@@ -137,7 +137,7 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
     p->kslabs = mode == PLAN_STEP_DENSE ? knot_slabs(B) : 1;
     p->bw_exp = take((size_t)Ks_learn);
     p->kpart = take((size_t)p->kslabs * 3 * (size_t)Ks_learn);
-    p->halo = take(STDADK_MAX_LEVELS);
+    p->halo = take((size_t)STDADK_MAX_LEVELS * HALO_SPLIT);
   }
   if (mode == PLAN_STEP_WINDOW) {
     p->G = pick_cell_grid(B);
@@ -913,9 +913,9 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
     // learnable knots: bandwidth = exp(log_bandwidth) (st_interp.py:146-148), and the candidate
     // windows follow wherever the knots are now
     a.g.bw = c.ws + pl.bw_exp;
-    rc = knot_halo(a.g, (int *)(c.ws + pl.halo), c.st, b->s_bw, c.ws + pl.bw_exp);   // also fills bw_exp
+    rc = knot_halo(a.g, c.ws + pl.halo, c.st, b->s_bw, c.ws + pl.bw_exp);   // also fills bw_exp
     if (rc) return rc;
-    a.halo = (const int *)(c.ws + pl.halo);
+    a.halo = c.ws + pl.halo;
   }
   a.xs = bb.xs; a.ys = bb.ys; a.ts = bb.ts; a.Xs = b->p > 0 ? bb.X_s : nullptr;
   a.B = (int)c.B; a.H = c.d->hidden[0];

@@ -57,8 +57,9 @@ struct L1FwdArgs {
   const int *step_dev;
   int rows_per_wg, n_wg;
   // free (learnable) knots: per-level half-width R of the candidate window around the observation's
-  // grid cell, device ints written by knot_halo() every step; NULL = fixed grid knots (R = 3)
-  const int *halo;
+  // grid cell, from the device floats [level][HALO_SPLIT] written by knot_halo() every step (see
+  // halo_half_width); NULL = fixed grid knots (R = 3)
+  const float *halo;
 };
 
 // z0 = [X|phi|psi] W0 + b0 -> LN -> ReLU -> Dropout for sorted observations; also writes psi.
@@ -82,7 +83,8 @@ struct L1BwdArgs {
 // candidate window that is guaranteed to contain every knot whose support reaches an observation,
 // wherever the learnable knots have moved and however their bandwidths have changed.
 // With log_bw the bandwidths are taken as exp(log_bw) and also written to bw_out (one launch for both).
-int knot_halo(const GridView &g, int *halo, hipStream_t st, const float *log_bw = nullptr, float *bw_out = nullptr);
+constexpr int HALO_SPLIT = 16;     // workgroups (partial maxima) per level
+int knot_halo(const GridView &g, float *halo, hipStream_t st, const float *log_bw = nullptr, float *bw_out = nullptr);
 
 // dW0T[p + k, :] = sum_b phi[b,k] dZ[b,:] for every spatial knot k (each knot row owned by one
 // wave: no atomics, summation in sorted-observation order => bitwise reproducible).

@@ -326,16 +326,21 @@ __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
   l1_window_fwd_body<CPL, LN, BASIS, FREE>(a, smem, r0, min(r0 + a.rows_per_wg, a.B));
 }
 
-// one workgroup per level: R = ceil(max_k (s_k + |c_k - grid_k|_inf) (side-1) + eps), clamped to [1, side]
+// HALO_SPLIT workgroups per level: each takes a slice of the level's knots and writes the slice's
+// max_k (s_k + |c_k - grid_k|_inf) (side-1) to halo[level][slice]; the consumer (halo_half_width in
+// l1_body.h) takes the max of a level's HALO_SPLIT values and rounds it up to the half-width R.
 // log_bw (optional): the bandwidths are given as logs; the kernel then also writes exp(log_bw) to bw_out
 // (the table the window kernels read), saving the separate exp launch
-__global__ __launch_bounds__(256) void knot_halo_kernel(GridView g, int *__restrict__ halo,
+__global__ __launch_bounds__(256) void knot_halo_kernel(GridView g, float *__restrict__ halo,
                                                         const float *__restrict__ log_bw, float *__restrict__ bw_out) {
-  const int l = blockIdx.x;
+  const int l = blockIdx.x, slice = blockIdx.y;
   const int side = g.side[l], off = g.off[l];
+  const int nk = side * side;
+  const int per = (nk + HALO_SPLIT - 1) / HALO_SPLIT;
+  const int j0 = slice * per, j1 = min(j0 + per, nk);
   const float sm1 = (float)(side > 1 ? side - 1 : 1);
   float m = 0.f;
-  for (int j = threadIdx.x; j < side * side; j += 256) {
+  for (int j = j0 + threadIdx.x; j < j1; j += 256) {
     const int k = off + j;
     const int ix = j / side, iy = j - ix * side;
     const float gx = side > 1 ? (float)ix / sm1 : 0.f, gy = side > 1 ? (float)iy / sm1 : 0.f;
@@ -350,16 +355,12 @@ __global__ __launch_bounds__(256) void knot_halo_kernel(GridView g, int *__restr
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float r = ceilf(m + 1e-3f);
-    halo[l] = r >= (float)side ? side : (r < 1.f ? 1 : (int)r);
-  }
+  if (threadIdx.x == 0) halo[l * HALO_SPLIT + slice] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-int knot_halo(const GridView &g, int *halo, hipStream_t st, const float *log_bw, float *bw_out) {
+int knot_halo(const GridView &g, float *halo, hipStream_t st, const float *log_bw, float *bw_out) {
   STDADK_REQUIRE(!log_bw || bw_out, STDADK_E_ARG, "knot_halo: log_bw needs bw_out");
-  STDADK_LAUNCH(knot_halo_kernel, dim3((unsigned)g.n_levels), dim3(256), 0, st, g, halo, log_bw, bw_out);
+  STDADK_LAUNCH(knot_halo_kernel, dim3((unsigned)g.n_levels, HALO_SPLIT), dim3(256), 0, st, g, halo, log_bw, bw_out);
   STDADK_CHECK_LAUNCH("knot_halo");
   return 0;
 }
