@@ -1368,3 +1368,44 @@ def test_fused_step_kernels_window_vs_materialised(variant):
     assert abs(res[0][1] - res[1][1]) <= 2e-5 * max(1.0, abs(res[1][1])), (res[0][1], res[1][1])
     err = rel_l2(res[0][0], res[1][0])
     assert err <= 5e-5, err
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_configs_window_vs_materialised(seed):
+    """Seeded random model / batch shapes (levels, widths, covariates, outputs, LayerNorm, dropout off,
+    learnable or fixed knots, batch size incl. > 4096): two engine steps on the window path against the
+    materialising kernels."""
+    from stnf.models import STInterpMLP
+    from stnf.engine import TrainStep
+    d = dev()
+    rs = np.random.RandomState(1000 + seed)
+    n_lev = int(rs.randint(1, 5))
+    sides = sorted(int(s) for s in rs.choice([12, 16, 20, 24, 33, 40, 48], size=n_lev, replace=False))
+    if sum(s * s for s in sides) < 1024:
+        sides[-1] = 40
+    h0 = int(rs.choice([128, 256]))
+    hidden = [h0] + [int(h) for h in rs.choice([32, 64, 128, 256], size=int(rs.randint(0, 3)))]
+    Q = int(rs.choice([1, 1, 2, 5]))
+    kw = dict(p=int(rs.choice([0, 0, 2])), k_spatial_centers=[s * s for s in sides],
+              k_temporal_centers=[int(k) for k in rs.choice([4, 7, 10, 15], size=int(rs.randint(1, 3)))],
+              hidden_dims=hidden, dropout=0.0, layernorm=bool(rs.randint(0, 2)),
+              spatial_basis_function=str(rs.choice(["wendland", "triangular"])), output_dim=Q,
+              spatial_learnable=bool(rs.randint(0, 2)))
+    B = int(rs.choice([17, 300, 1500, 4096, 5000, 9000]))
+    coords = torch.from_numpy(rs.uniform(-0.01, 1.01, (B, 2)).astype(np.float32)).to(d)
+    t = torch.from_numpy(rs.uniform(0, 1, (B,)).astype(np.float32)).to(d)
+    y = torch.from_numpy(rs.standard_normal((B, Q)).astype(np.float32)).to(d)
+    X = torch.from_numpy(rs.standard_normal((B, kw["p"])).astype(np.float32)).to(d) if kw["p"] else None
+    res = []
+    for dense in (False, True):
+        torch.manual_seed(seed)
+        m = STInterpMLP(**kw).to(d)
+        m.train()
+        eng = TrainStep(m, lr=1e-3, grad_clip=5.0, ema_decay=0.9, max_batch=B, force_dense=dense)
+        assert eng.uses_window == (not dense), (kw, B)
+        for _ in range(2):
+            eng.step(X, coords, t, y)
+        res.append((eng.flat.clone().cpu().numpy(), eng.mean_loss()))
+    assert abs(res[0][1] - res[1][1]) <= 2e-5 * max(1.0, abs(res[1][1])), (kw, B, res[0][1], res[1][1])
+    err = rel_l2(res[0][0], res[1][0])
+    assert err <= 1e-4, (kw, B, err)
