@@ -207,9 +207,10 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
     for (int j = lane; j < Kt; j += 64) {
       float v = psi_eval(t, a.g.t_centers[j], a.g.t_bw[j]);
       my_psi[j] = v;
-      a.psi[(size_t)row * a.ld_psi + j] = v;
+      if (a.psi) a.psi[(size_t)row * a.ld_psi + j] = v;
     }
-    for (int j = Kt + lane; j < a.ld_psi; j += 64) a.psi[(size_t)row * a.ld_psi + j] = 0.f;
+    if (a.psi)
+      for (int j = Kt + lane; j < a.ld_psi; j += 64) a.psi[(size_t)row * a.ld_psi + j] = 0.f;
     __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < Kt; ++j) fma_row<CPL>(acc, my_psi[j], Wt + (size_t)j * H + CPL * lane);
     __builtin_amdgcn_wave_barrier();
@@ -225,7 +226,7 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
 #pragma unroll
       for (int c = 0; c < CPL; ++c) { float d = acc[c] - mean; sq += d * d; }
       rs = 1.0f / sqrtf(wave_sum(sq) / (float)H + a.eps);
-      if (lane == 0) a.rstd[row] = rs;
+      if (lane == 0 && a.rstd) a.rstd[row] = rs;
     }
     float xh[CPL], av[CPL];
 #pragma unroll
@@ -243,7 +244,7 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
     float *f1 = reinterpret_cast<float *>(&o1), *f2 = reinterpret_cast<float *>(&o2);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) { f1[c] = xh[c]; f2[c] = av[c]; }
-    *reinterpret_cast<typename VecT<CPL>::T *>(a.xhat + (size_t)row * H + CPL * lane) = o1;
+    if (a.xhat) *reinterpret_cast<typename VecT<CPL>::T *>(a.xhat + (size_t)row * H + CPL * lane) = o1;
     *reinterpret_cast<typename VecT<CPL>::T *>(a.act + (size_t)row * H + CPL * lane) = o2;
   }
 }

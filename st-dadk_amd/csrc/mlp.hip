@@ -489,6 +489,7 @@ struct Ctx {
   bool l1_pend_valid = false;   // window path, B <= 4096: the layer-0 launch is parked as well
   L1FwdArgs l1_pend;
   int l1_basis = 0;
+  bool save = true;             // false in eval mode: the forward keeps nothing for a backward (xhat, rstd, act, psi)
   bool log_bw = false;          // basis->s_bw holds log-bandwidths (learnable knots)
   const int64_t *idx = nullptr; // window path: the batch is rows idx[b] of the resident observation arrays
   bool prebinned = false;       // window path: stdadk_bin_batch_f32 already filled the workspace's bins
@@ -610,6 +611,7 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
       STDADK_REQUIRE(P->W[i] && P->b[i] && (!d->layernorm || (P->ln_g[i] && P->ln_b[i])), STDADK_E_ARG,
                      "mlp_forward: layer %d parameters NULL", i);
       a.L[i - l] = tail_layer(c, i);
+      if (!c.save) a.L[i - l].xhat = a.L[i - l].rstd = a.L[i - l].act = nullptr;
     }
     a.a_in = ws + pl.act[l - 1];
     a.h_in = d->hidden[l - 1];
@@ -925,6 +927,7 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
   a.eps = c.d->ln_eps;
   a.xhat = c.ws + pl.xhat[0]; a.rstd = c.ws + pl.rstd[0]; a.act = c.ws + pl.act[0];
   a.psi = c.ws + pl.psi; a.ld_psi = pl.ld_psi;
+  if (!c.save) a.xhat = a.rstd = a.psi = nullptr;      // act stays: it is the input of the next layer
   a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
   a.rows_per_wg = 0; a.n_wg = 0;
   STDADK_REQUIRE(a.W0T && a.b0, STDADK_E_ARG, "window forward: layer 0 weights NULL");
@@ -1158,6 +1161,7 @@ extern "C" int stdadk_forward_f32(const stdadk_basis_desc *b, const stdadk_mlp_d
   STDADK_REQUIRE(b->p == 0 || X, STDADK_E_ARG, "forward: X is NULL with p=%d", b->p);
   c.P = P; c.G = nullptr; c.st = (hipStream_t)stream;
   c.dp = training ? d->dropout_p : 0.f; c.seed = drop_seed; c.step_dev = step_dev;
+  c.save = training != 0;
   return step_forward(c, b, window, coords, t, X, nullptr, y_pred, stream);
 }
 

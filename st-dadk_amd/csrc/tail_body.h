@@ -235,7 +235,7 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
           sq += d * d;
         }
         rs = 1.0f / sqrtf(wave_sum(sq) / (float)h + a.eps);
-        if (lane == 0 && grow < a.B) L.rstd[grow] = rs;
+        if (lane == 0 && grow < a.B && L.rstd) L.rstd[grow] = rs;
       }
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
@@ -249,7 +249,7 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
         }
         if (col < h) {
           nxt[row * ACT_LD + col] = v;
-          if (grow < a.B) {
+          if (grow < a.B && L.xhat) {          // NULL in eval mode: nothing is kept for a backward
             L.xhat[(size_t)grow * h + col] = xh;
             L.act[(size_t)grow * h + col] = v;
           }

@@ -50,7 +50,7 @@ struct L1FwdArgs {
   const float *W0T;     // [D][H]
   const float *b0, *gamma, *beta;
   float eps;
-  float *xhat, *rstd, *act, *psi;
+  float *xhat, *rstd, *act, *psi;   // xhat / rstd / psi may be NULL (eval mode: kept only for a backward)
   int ld_psi;
   float drop_p;
   uint64_t seed;
