@@ -379,12 +379,12 @@ def main():
                             output_dim=5),
                 dict(loss="pinball", quantile_levels=taus, non_crossing_weight=0.5, domain_penalty_weight=0.01))
             out["variants"]["ref_default_227_uniform_mse"] = timed(B, 60, dict(k_spatial_centers=[25, 81, 121]))
-            # A10: dense-grid inference (forward only, eval mode, hipGraph per 65 536-row chunk) on the
+            # A10: dense-grid inference (forward only, eval mode) on the
             # resident observations, as the dense-grid prediction callers run it
             from stnf.engine import Predictor
             model.eval()
-            pr = Predictor(model, chunk=65536)
-            n_inf = min(n_obs, 65536) if n_obs < 2 * 65536 else n_obs // 65536 * 65536
+            pr = Predictor(model)                               # default chunk (262 144 rows), eager launches
+            n_inf = n_obs
             ci, ti = coords[:n_inf].contiguous(), t[:n_inf].contiguous()
             for _ in range(3):
                 pr.predict(ci, ti)
