@@ -32,3 +32,33 @@ def compute_metrics(y_true: Union[np.ndarray, torch.Tensor], y_pred: Union[np.nd
             ma.append(float(mae_h))
         out['rmse_per_horizon'], out['mae_per_horizon'] = rm, ma
     return out
+
+
+def compute_spatial_metrics(y_true, y_pred, coords, n_bins: int = 5) -> Dict[str, list]:
+    """RMSE / MAE per ring of distance from the origin (reference stnf/utils/metrics.py:67-146): sites
+    (axis 2 of the (B,H,S,1) arrays) are grouped into `n_bins` equal-width rings of |coords|, empty rings
+    are skipped, NaNs ignored.  Returns bin_centers / rmse_by_distance / mae_by_distance."""
+    yt, yp = _np(y_true), _np(y_pred)
+    dist = np.hypot(np.asarray(coords)[:, 0], np.asarray(coords)[:, 1])
+    edges = np.linspace(0, dist.max(), n_bins + 1)
+    out = {'bin_centers': [], 'rmse_by_distance': [], 'mae_by_distance': []}
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        sel = (dist >= lo) & (dist < hi)
+        if not sel.any():
+            continue
+        a, b = yt[:, :, sel, :].ravel(), yp[:, :, sel, :].ravel()
+        ok = ~(np.isnan(a) | np.isnan(b))
+        err = a[ok] - b[ok]
+        out['rmse_by_distance'].append(float(np.sqrt(np.mean(err ** 2))) if err.size else float('nan'))
+        out['mae_by_distance'].append(float(np.mean(np.abs(err))) if err.size else float('nan'))
+        out['bin_centers'].append(float((lo + hi) / 2))
+    return out
+
+
+def print_metrics(metrics: Dict[str, float], prefix: str = ""):
+    """Human-readable dump of compute_metrics' output (reference :149-164)."""
+    print(f"{prefix} Metrics:")
+    for label, key in (("RMSE:", 'rmse'), ("MAE: ", 'mae'), ("R²:  ", 'r2')):
+        print(f"  {label} {metrics[key]:.6f}")
+    if 'rmse_per_horizon' in metrics:
+        print(f"  RMSE per horizon: {metrics['rmse_per_horizon']}")

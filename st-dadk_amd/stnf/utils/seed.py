@@ -1,4 +1,6 @@
-"""Seed fixing (reference stnf/utils/seed.py:9-27)."""
+"""One seed for every generator the driver uses: Python's `random`, numpy's global RandomState and
+torch (host generator plus every HIP device).  Counterpart of the reference's stnf/utils/seed.py:9-27;
+the cuDNN determinism switches it sets have no meaning on ROCm and are left out."""
 import random
 
 import numpy as np
@@ -6,9 +8,8 @@ import torch
 
 
 def set_seed(seed: int):
-    random.seed(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)          # also seeds every HIP device generator
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
     print(f"[INFO] Seed set to {seed}")

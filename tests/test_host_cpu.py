@@ -303,3 +303,18 @@ def test_graft_entry_build_imports_and_checks_abi():
     g.build()
     hdr = open(os.path.join(ROOT, "include", "stdadk.h")).read()
     assert int(re.search(r"#define STDADK_ABI_VERSION (\d+)", hdr).group(1)) == N.ABI_VERSION
+
+
+def test_spatial_metrics_and_print(capsys):
+    """compute_spatial_metrics / print_metrics (reference stnf/utils/metrics.py:67-164) on a hand-checked case."""
+    from stnf.utils import compute_spatial_metrics, print_metrics, compute_metrics
+    coords = np.array([[0.0, 0.0], [0.3, 0.4], [0.6, 0.8], [0.6, 0.8]])          # |.| = 0, 0.5, 1, 1
+    yt = np.zeros((1, 2, 4, 1)); yp = np.zeros((1, 2, 4, 1))
+    yp[:, :, 1, :] = 2.0; yp[0, 0, 0, 0] = np.nan
+    sm = compute_spatial_metrics(yt, yp, coords, n_bins=2)
+    # rings [0,0.5) -> site 0 (one NaN dropped, error 0), [0.5,1.0) -> site 1 (error 2); |c| = 1 sits on the open edge
+    assert sm['bin_centers'] == [0.25, 0.75]
+    assert sm['rmse_by_distance'] == [0.0, 2.0] and sm['mae_by_distance'] == [0.0, 2.0]
+    print_metrics(compute_metrics(np.array([1.0, 2.0, 3.0]), np.array([1.0, 2.0, 4.0])), prefix="Val")
+    out = capsys.readouterr().out
+    assert out.startswith("Val Metrics:") and "RMSE: 0.577350" in out and "R²:" in out
