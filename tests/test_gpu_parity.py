@@ -1409,3 +1409,25 @@ def test_random_configs_window_vs_materialised(seed):
     assert abs(res[0][1] - res[1][1]) <= 2e-5 * max(1.0, abs(res[1][1])), (kw, B, res[0][1], res[1][1])
     err = rel_l2(res[0][0], res[1][0])
     assert err <= 1e-4, (kw, B, err)
+
+
+@pytest.mark.parametrize("switch", ["STDADK_NO_L1_TAIL", "STDADK_NO_TAIL_FWD_BWD", "STDADK_NO_DW_ALL"])
+def test_launch_fusions_are_bitwise_neutral(switch, monkeypatch):
+    """The fused launches run the same kernel bodies as the separate ones: switching a fusion off
+    (library environment switch, read per call) leaves the parameters after three steps bit-identical."""
+    from stnf.engine import TrainStep
+    d = dev()
+    cfg = cases.MODEL_CASES["c2_b257"]
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv(switch, "1")
+        m = build_model(cfg, dropout=0.1)
+        m.train()
+        eng = TrainStep(m, lr=1e-3, ema_decay=0.99, max_batch=cfg["B"])
+        for _ in range(3):
+            eng.step(None, coords, t, y)
+        res.append(eng.flat.clone())
+    monkeypatch.delenv(switch, raising=False)
+    assert torch.equal(res[0], res[1])
