@@ -342,6 +342,32 @@ int stdadk_train_fwd_bwd_indexed_f32(const stdadk_basis_desc *basis, const stdad
                                      const int32_t *step_dev, int32_t flags, stdadk_stream_t stream,
                                      stdadk_stream_t aux_stream);
 
+/* A0 + A2-A9 in ONE call (single GPU): stdadk_train_fwd_bwd(_indexed)_f32, then clip_grad_norm_ +
+ * AdamW + EMA (stdadk_sumsq_f32 + stdadk_adamw_ema_f32) on the flat buffers of `opt`, whose gradient
+ * buffer [g, g+n) must contain every tensor of `grads` (gaps zero).  Knowing the whole step lets the
+ * library take the gradient's squared norm out of the launches that produce it (window path: no
+ * separate pass over the gradient); otherwise it runs the separate kernels.  idx may be NULL (rows
+ * 0..B-1 of the given arrays).  opt->step_dev (device int32, required) is read by dropout and AdamW and
+ * advanced once.  Data-parallel training keeps the split calls: the all-reduce sits between them. */
+#define STDADK_GRADSQ_PARTS 512
+typedef struct stdadk_optim_desc {
+  float *p, *g, *m, *v, *ema;   /* flat fp32 buffers of n elements; ema may be NULL                 */
+  int64_t n;
+  float lr;                     /* used when lr_dev is NULL                                        */
+  const float *lr_dev;
+  float beta1, beta2, eps, weight_decay;
+  int32_t *step_dev;            /* device step counter (starts at 0)                               */
+  float max_norm;               /* clip_grad_norm_ threshold; <= 0: no clipping                    */
+  float *sumsq_parts;           /* [STDADK_GRADSQ_PARTS] device scratch                            */
+  float ema_decay;
+} stdadk_optim_desc;
+int stdadk_train_step_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                          const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,
+                          const float *coords, const float *t, const float *X, const float *y,
+                          const int64_t *idx, int64_t B, float grad_scale, const stdadk_loss_desc *loss,
+                          float *loss_sum, void *workspace, size_t workspace_bytes, uint64_t drop_seed,
+                          int32_t flags, const stdadk_optim_desc *opt, stdadk_stream_t stream);
+
 /* A0, window path: the batch-preparation half of the step on its own — gathers rows idx[b] (NULL = rows
  * 0..B-1) of coords_all / t_all / X_all / y_all [N, y_cols] and bins them into `workspace`, exactly as
  * the step entry points would.  Software pipelining: call it for batch k+1 on a second stream (and a

@@ -42,11 +42,21 @@ struct ReduceJob {
   int wide = 0;       // set by launch_reduce_jobs
 };
 constexpr int REDUCE_GROUP_MAX = 40;
+constexpr int REDUCE_SQ_PARTS = 512;   // = STDADK_GRADSQ_PARTS
 struct ReduceGroup {
   int n = 0;
   ReduceJob job[REDUCE_GROUP_MAX];
   int first_block[REDUCE_GROUP_MAX + 1];
+  // optional (sq_parts != NULL): partial sums of squares of every value this launch writes, plus of an
+  // already final region sq_src[0..sq_n) — together the squared norm of a whole gradient.
+  // sq_parts[0..256): the region (256 extra workgroups); [256..512): one per reduce workgroup, zero beyond.
+  float *sq_parts = nullptr;
+  const float *sq_src = nullptr;
+  int64_t sq_n = 0;
+  int *step_inc = nullptr;       // advanced by one (device step counter), or NULL
+  int n_reduce_blocks = 0;       // set by launch_reduce_jobs
 };
+int reduce_jobs_block_count(ReduceGroup &grp);    // fills first_block / wide; the launch's reduce workgroups
 int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st);     // every job: a_km = b_km = true, aligned
 int gemm_tn_grouped_prepare(GemmGroup &grp, int *n_blocks);     // fills first_block; for launches that embed the group
 int launch_reduce_jobs(ReduceGroup &grp, hipStream_t st);

@@ -483,6 +483,11 @@ struct Ctx {
   // with the backward chain as ONE kernel (the tail of a row tile is row-local through the loss)
   bool fuse_tail = false, pend_valid = false;
   TailFwdArgs pend;
+  // whole-step entry (stdadk_train_step_f32): squared-norm partials of the gradient ride along with the
+  // reductions launch when every gradient is produced by it or by the per-knot gather
+  float *gradsq = nullptr;      // [STDADK_GRADSQ_PARTS] or NULL
+  int *step_inc = nullptr;
+  bool gradsq_done = false, all_grouped = true;
   bool merge_dw = false, dw_pend = false;   // window path: grouped dW products + per-knot gather as one launch
   GemmGroup gg_pend;
   ReduceGroup rg_pend;
@@ -717,6 +722,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
         add_reduce(g.slab, C, M * N, g.splits, g.slab_stride);
         return 0;
       }
+      c.all_grouped = false;
       return gemm_run(A, lda, true, Bm, ldb, true, M, N, (int)B, nullptr, C, N, slab + slab_off, false, nullptr, st);
     };
     add_reduce(part, G->W[L], Q * hL, (int)nb16, (int64_t)Q * (hL + 1));
@@ -1135,6 +1141,15 @@ static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const 
     c.dw_pend = false;
     rc = window_dw0(c, c.st, &c.gg_pend);
     if (rc) return rc;
+    if (c.gradsq && c.all_grouped && reduce_jobs_block_count(c.rg_pend) <= 256) {
+      // every gradient of the step is either an output of this launch or a spatial row of dW0^T (final
+      // after the launch above): their squared norm comes out of the same launch
+      c.rg_pend.sq_parts = c.gradsq;
+      c.rg_pend.sq_src = c.G->W[0] + (size_t)b->p * H;
+      c.rg_pend.sq_n = (int64_t)b->Ks * H;
+      c.rg_pend.step_inc = c.step_inc;
+      c.gradsq_done = true;
+    }
     return launch_reduce_jobs(c.rg_pend, c.st);
   }
   for (int e = 0; e < c.n_extra; ++e) {     // not consumed by a grouped launch
@@ -1241,9 +1256,13 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
                               const stdadk_loss_desc *loss, float *loss_sum,
                               float *y_pred, void *workspace, size_t workspace_bytes,
                               uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
-                              stdadk_stream_t stream, stdadk_stream_t aux_stream) {
+                              stdadk_stream_t stream, stdadk_stream_t aux_stream,
+                              float *gradsq_parts = nullptr, int32_t *step_inc = nullptr,
+                              bool *gradsq_done = nullptr) {
   if (B == 0) return 0;
   Ctx c;
+  c.gradsq = gradsq_parts; c.step_inc = step_inc;
+  struct Done { Ctx &c; bool *out; ~Done() { if (out) *out = c.gradsq_done; } } done_guard{c, gradsq_done};
   bool window;
   int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
   if (rc) return rc;
@@ -1291,6 +1310,39 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
   rc = step_backward(c, b, false, c.ws + c.pl.dY, false);
   STDADK_REQUIRE(rc || !c.pend_valid, STDADK_E_ARG, "train_fwd_bwd: the parked tail launch was never issued");
   return rc;
+}
+
+extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                     const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
+                                     const float *coords, const float *t, const float *X, const float *y,
+                                     const int64_t *idx, int64_t B, float grad_scale,
+                                     const stdadk_loss_desc *loss, float *loss_sum, void *workspace,
+                                     size_t workspace_bytes, uint64_t drop_seed, int32_t flags,
+                                     const stdadk_optim_desc *o, stdadk_stream_t stream) {
+  STDADK_REQUIRE(o && o->p && o->g && o->m && o->v && o->n > 0 && o->step_dev, STDADK_E_ARG,
+                 "train_step: optimiser descriptor incomplete");
+  STDADK_REQUIRE(o->max_norm <= 0.f || o->sumsq_parts, STDADK_E_ARG, "train_step: max_norm > 0 needs sumsq_parts");
+  if (B == 0) return 0;
+  const bool clip = o->max_norm > 0.f;
+  bool sq_done = false;
+  int rc = train_fwd_bwd_impl(b, d, P, G, coords, t, X, y, idx, B, grad_scale, loss, loss_sum, nullptr, workspace,
+                              workspace_bytes, drop_seed, o->step_dev, flags, stream, nullptr,
+                              clip ? o->sumsq_parts : nullptr, clip ? o->step_dev : nullptr, &sq_done);
+  if (rc) return rc;
+  int n_parts = 0;
+  if (clip && sq_done) {
+    n_parts = STDADK_GRADSQ_PARTS;                 // partials (and the step advance) came out of the reductions launch
+  } else if (clip) {
+    rc = stdadk_sumsq_f32(o->g, o->n, o->sumsq_parts, o->step_dev, stream);
+    if (rc) return rc;
+    n_parts = STDADK_SUMSQ_PARTS;
+  } else {
+    rc = stdadk_step_advance(o->step_dev, stream);
+    if (rc) return rc;
+  }
+  return stdadk_adamw_ema_f32(o->p, o->g, o->m, o->v, o->ema, o->n, o->lr, o->lr_dev, o->beta1, o->beta2, o->eps,
+                              o->weight_decay, 1, o->step_dev, o->max_norm, clip ? o->sumsq_parts : nullptr, n_parts,
+                              1.0f, o->ema_decay, stream);
 }
 
 extern "C" int stdadk_bin_batch_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,

@@ -48,6 +48,16 @@ class LossDesc(C.Structure):
                 ("nc_weight", C.c_float), ("nc_power", C.c_int32)]
 
 
+GRADSQ_PARTS = 512
+
+
+class OptimDesc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("lr_dev", C.c_void_p), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step_dev", C.c_void_p),
+                ("max_norm", C.c_float), ("sumsq_parts", C.c_void_p), ("ema_decay", C.c_float)]
+
+
 class AdamGroup(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_float), ("lr_dev", C.c_void_p), ("max_norm", C.c_float),
@@ -93,6 +103,11 @@ _SIGNATURES = {
     "stdadk_delta_head_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                  C.c_int32, C.c_int32, C.c_float, C.c_float,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stdadk_train_step_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
+                                        C.POINTER(MlpTensors), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_float, C.POINTER(LossDesc), C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_uint64, C.c_int32, C.POINTER(OptimDesc),
+                                        C.c_void_p]),
     "stdadk_sumsq2_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "stdadk_adamw_ema2_f32": (C.c_int, [C.POINTER(AdamGroup), C.POINTER(AdamGroup), C.c_float, C.c_float,
@@ -536,6 +551,34 @@ def adamw_ema(p, g, m, v, ema, lr, betas, eps, weight_decay, step, max_norm=0.0,
                                     0 if sumsq_parts is None else sumsq_parts.numel(),
                                     grad_mul, ema_decay, _stream())
     _check(rc, "stdadk_adamw_ema_f32")
+
+
+def make_optim(p, g, m, v, ema, lr, lr_dev, betas, eps, weight_decay, step_dev, max_norm, sumsq_parts, ema_decay):
+    o = OptimDesc()
+    o.p, o.g, o.m, o.v, o.ema = _dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), _dev(ema, "ema")
+    o.n = p.numel()
+    o.lr, o.lr_dev = float(lr), _dev(lr_dev, "lr_dev")
+    o.beta1, o.beta2, o.eps, o.weight_decay = float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+    o.step_dev = _dev(step_dev, "step_dev")
+    o.max_norm = float(max_norm)
+    if sumsq_parts is not None and sumsq_parts.numel() != GRADSQ_PARTS:
+        raise RuntimeError(f"make_optim: sumsq_parts must hold {GRADSQ_PARTS} floats")
+    o.sumsq_parts = _dev(sumsq_parts, "sumsq_parts")
+    o.ema_decay = float(ema_decay)
+    return o
+
+
+def train_step(basis, desc, params, grads, coords, t, X, y, idx, B, grad_scale, loss_sum, workspace, flags, optim,
+               seed=0, loss_desc=None):
+    """The whole single-GPU step in one call: forward, objective, backward, clip + AdamW + EMA."""
+    if idx is not None and (idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous()):
+        raise RuntimeError("train_step: idx must be a contiguous int64 tensor on the device")
+    rc = lib().stdadk_train_step_f32(
+        C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads), _dev(coords, "coords"), _dev(t, "t"),
+        _dev(X, "X"), _dev(y, "y"), idx.data_ptr() if idx is not None else None, B, grad_scale,
+        C.byref(loss_desc) if loss_desc is not None else None, _dev(loss_sum, "loss_sum"), workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), seed, flags, C.byref(optim), _stream())
+    _check(rc, "stdadk_train_step_f32")
 
 
 def sumsq2(g0, parts0, g1, parts1, step_inc=None):

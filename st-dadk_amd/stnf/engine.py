@@ -211,6 +211,12 @@ class TrainStep:
         self._warm = False
         self._ix = None
         self._ix_graph = None
+        # the one-call step applies with a single parameter group on one GPU (data-parallel training needs
+        # the all-reduce between backward and optimiser; learnable knots / the delta head have extra kernels there)
+        self._whole_step = (not self.distributed and not self.learnable and not model._has_delta
+                            and self.aux_stream is None)
+        self._optim = None
+        self._sumsq512 = torch.zeros(N.GRADSQ_PARTS, device=self.dev)
         self._pipe = None          # two workspaces + side stream of the pipelined batch preparation
         self._prepared = None      # ((idx data_ptr, numel), workspace index, idx tensor) of the announced batch
 
@@ -235,6 +241,17 @@ class TrainStep:
         ws = self.ws if ws is None else ws
         flags = st.flags | (N.FLAG_PREBINNED if prebinned else 0)
         Q = self.model.output_dim
+        if self._whole_step:
+            # single GPU, one parameter group: the whole step is ONE library call, which also takes the
+            # gradient's squared norm out of the launches that produce it (no separate pass over it)
+            if self._optim is None:
+                self._optim = N.make_optim(self.flat, self.grad, self.m, self.v, self.ema, self.lr, self.lr_dev,
+                                           self.betas, self.eps, self.wd, self.step_dev, self.grad_clip,
+                                           self._sumsq512 if self.grad_clip > 0 else None, self.ema_decay)
+            N.train_step(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y,
+                         idx if not prebinned else None, B, D.grad_scale(global_rows, Q), self.loss_sum, ws, flags,
+                         self._optim, seed=self.seed, loss_desc=self._loss_desc(y.shape[1]))
+            return
         if st.head is not None:
             N.delta_head(st.delta, st.head[0], st.head[1])          # output layer of this step's delta
         # d(mean over the GLOBAL batch)/dparams: each rank scales by 1/global_rows, the all-reduce SUMs

@@ -632,7 +632,46 @@ def test_engine_two_streams_equals_one():
         torch.cuda.synchronize()
         res.append((eng.mean_loss(), eng.flat.clone()))
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])   # the loss is summed with float atomics
-    assert torch.equal(res[0][1], res[1][1])      # parameters: same kernels, same order of every sum
+    # Same kernels and the same order of every gradient sum; only the clip norm differs in its last bits
+    # (one stream: partials out of the reductions launch, 512 of them; two streams: stdadk_sumsq_f32, 256).
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name,dense,clip", [("c2_b257", False, 1.0), ("c2_b257", False, 0.0),
+                                             ("default227", True, 1.0), ("c2_b257_mq3", False, 1.0),
+                                             ("tiny9_mq5_nc2", False, 1.0)])
+def test_one_call_step_equals_split_calls(name, dense, clip):
+    """stdadk_train_step_f32 (forward, objective, backward, clip + AdamW + EMA in one call, the clip norm
+    taken from the reductions launch) against the same step issued as stdadk_train_fwd_bwd_f32 +
+    stdadk_sumsq_f32 + stdadk_adamw_ema_f32.  The dense path has gradients the reductions launch does not
+    produce, so the entry falls back to the separate norm pass there."""
+    from stnf.engine import TrainStep
+    d = dev()
+    res = []
+    for whole in (True, False):
+        kw = {}
+        if name in cases.MODEL_CASES:
+            cfg = cases.MODEL_CASES[name]
+            m = build_model(cfg)
+        else:
+            m, cfg, lc = build_quantile_model(name)
+            kw = dict(loss="pinball", quantile_levels=lc["taus"], non_crossing_weight=lc.get("nc_weight", 0.0),
+                      non_crossing_power=lc.get("nc_power", 1))
+        X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+        eng = TrainStep(m, lr=1e-2, ema_decay=0.99, grad_clip=clip, max_batch=cfg["B"], force_dense=dense, **kw)
+        assert eng._whole_step
+        eng._whole_step = whole
+        for _ in range(3):
+            eng.step(X if cfg["p"] else None, coords, t, y)
+        torch.cuda.synchronize()
+        assert int(eng.step_dev.item()) == 3
+        res.append((eng.mean_loss(), eng.flat.clone(), eng.ema.clone()))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
+    if clip == 0.0:
+        assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    else:   # the squared norm is summed in a different order
+        torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(res[0][2], res[1][2], rtol=2e-6, atol=1e-7)
 
 
 def test_reference_style_loop_matches_engine():
@@ -1425,7 +1464,9 @@ def test_launch_fusions_are_bitwise_neutral(switch, monkeypatch):
             monkeypatch.setenv(switch, "1")
         m = build_model(cfg, dropout=0.1)
         m.train()
-        eng = TrainStep(m, lr=1e-3, ema_decay=0.99, max_batch=cfg["B"])
+        # no clipping: where the clip norm's partials are summed (inside the reductions launch, or a
+        # separate pass when that launch is split up) changes its last bits, which is not the point here
+        eng = TrainStep(m, lr=1e-3, ema_decay=0.99, max_batch=cfg["B"], grad_clip=0.0)
         for _ in range(3):
             eng.step(None, coords, t, y)
         res.append(eng.flat.clone())

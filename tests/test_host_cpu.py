@@ -239,6 +239,8 @@ def test_n3_host_surface():
     assert ctypes.sizeof(N.LossDesc) == 4 * (2 + 8 + 2)
     # stdadk_adam_group: 5 pointers, int64 n, float lr (+pad), pointer, float max_norm (+pad), pointer, int32 (+pad)
     assert ctypes.sizeof(N.AdamGroup) == 88 and N.AdamGroup.lr_dev.offset == 56 and N.AdamGroup.n_parts.offset == 80
+    # stdadk_optim_desc: 5 pointers, int64, float (+pad), pointer, 4 floats, pointer, float (+pad), pointer, float (+pad)
+    assert ctypes.sizeof(N.OptimDesc) == 112 and N.OptimDesc.step_dev.offset == 80 and N.OptimDesc.sumsq_parts.offset == 96
     # stdadk_knot_train: pointer, int32, 6 floats (+pad to 8)
     assert ctypes.sizeof(N.KnotTrain) == 40
     ld = N.make_loss("pinball", 3, 1, [0.1, 0.5, 0.9], 0.5, 2)
