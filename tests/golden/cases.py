@@ -96,6 +96,39 @@ BASIS_LR_RATIO = 0.05        # train_st_interp.py:475
 BASIS_CLIP_RATIO = 0.1       # train_st_interp.py:703
 
 
+# Sparsity penalties on the first layer's weights (st_interp.py:724-825, added to the loss by the batch
+# body at train_st_interp.py:674-691): element-wise L1, group lasso per basis function, or both.
+# `zero_rows`: basis columns of mlp.0.weight set to exactly 0 before the run (the sub-gradient torch takes
+# there is 0 for both |w| and the row norm) -- counted from the first spatial column.
+SPARSITY_CASES = {
+    "tiny9_sp_element": dict(base="tiny9", seed=51, zero_rows=[2],
+                             sp=dict(kind="element", lambda_l1=0.01, lambda_group=0.0)),
+    "tiny9_sp_group": dict(base="tiny9_ln_p3", seed=52, zero_rows=[0, 11],
+                           sp=dict(kind="group", lambda_l1=0.0, lambda_group=0.02, apply_temporal=False)),
+    "default227_sp_sg": dict(base="default227", seed=53, zero_rows=[5, 290],
+                             sp=dict(kind="sparse_group", lambda_l1=1e-3, lambda_group=1e-2)),
+    "c2_b257_sp_sg": dict(base="c2_b257", seed=54, zero_rows=[7, 4000, 10350],
+                          sp=dict(kind="sparse_group", lambda_l1=1e-4, lambda_group=1e-3,
+                                  apply_spatial=True, apply_temporal=True)),
+}
+
+
+def sparsity_cfg(name):
+    q = SPARSITY_CASES[name]
+    cfg = dict(MODEL_CASES[q["base"]])
+    cfg.update(seed=q["seed"])
+    return cfg, q["sp"], q["zero_rows"]
+
+
+def sparsity_state(cfg, zero_rows):
+    """make_state(cfg) with the listed basis columns of the first Linear zeroed."""
+    st = make_state(cfg)
+    k0 = next(iter(st))
+    for r in zero_rows:
+        st[k0][:, cfg["p"] + r] = 0.0
+    return st
+
+
 def learn_cfg(name):
     q = LEARN_CASES[name]
     cfg = dict(MODEL_CASES[q["base"]])

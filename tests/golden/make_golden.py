@@ -414,6 +414,83 @@ def gen_learn_case(name):
           f"domain={out['domain_pen64']:.4g} movement={out['movement_pen64']:.4g} ref fp32 err d_centers={gc:.2e}")
 
 
+# ---------------------------------------------------------------------------------------------
+# Sparsity penalties on the first layer, added to the loss as the batch body does
+# (train_st_interp.py:674-691) with the reference's own compute_sparsity_penalty
+# ---------------------------------------------------------------------------------------------
+def sp_loss(model, X, coords, t, y, sp):
+    loss = torch.nn.MSELoss()(model(X, coords, t), y)
+    pen = model.compute_sparsity_penalty(penalty_type=sp["kind"], lambda_l1=sp["lambda_l1"],
+                                         lambda_group=sp["lambda_group"])
+    if sp.get("apply_spatial", True):
+        loss = loss + pen["spatial_penalty"]
+    if sp.get("apply_temporal", True):
+        loss = loss + pen["temporal_penalty"]
+    return loss, pen
+
+
+def sp_build(cfg, zero_rows):
+    model = build(cfg)
+    sd = model.state_dict()
+    for k, v in cases.sparsity_state(cfg, zero_rows).items():
+        sd[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(sd)
+    return model
+
+
+def sp_run(model, X, coords, t, y, sp):
+    model.train()
+    model.zero_grad()
+    loss, pen = sp_loss(model, X, coords, t, y, sp)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    return loss.detach(), {k: v.detach() for k, v in pen.items()}, grads
+
+
+def sp_opt(model, X, coords, t, y, sp):
+    o = cases.OPT
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=o["lr"],
+                            weight_decay=o["weight_decay"], betas=o["betas"], eps=o["eps"])
+    ema = ModelEMA(model, decay=o["ema_decay"])
+    losses = []
+    model.train()
+    for _ in range(o["steps"]):
+        opt.zero_grad()
+        loss, _ = sp_loss(model, X, coords, t, y, sp)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), o["grad_clip"])
+        opt.step()
+        ema.update(model)
+        losses.append(float(loss))
+    params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    shadow = {n: v.detach().clone() for n, v in ema.shadow.items()}
+    return params, shadow, np.array(losses, dtype=np.float64)
+
+
+def gen_sparsity_case(name):
+    cfg, sp, zero_rows = cases.sparsity_cfg(name)
+    X, coords, t, y = (torch.from_numpy(a) for a in cases.make_inputs(cfg))
+    d = lambda a: a.double()
+    out = {}
+    l32, pen32, g32 = sp_run(sp_build(cfg, zero_rows), X, coords, t, y, sp)
+    l64, pen64, g64 = sp_run(sp_build(cfg, zero_rows).double(), d(X), d(coords), d(t), d(y), sp)
+    out["loss32"], out["loss64"] = np.float32(l32.item()), np.float64(l64.item())
+    for k in ("spatial_penalty", "temporal_penalty"):
+        out[k + "32"], out[k + "64"] = np.float32(pen32[k].item()), np.float64(pen64[k].item())
+    for k in g64:
+        store(out, "g", k, g64[k].numpy(), g32[k].numpy(), cfg["seed"] + 7, False)
+    p32, s32, lo32 = sp_opt(sp_build(cfg, zero_rows), X, coords, t, y, sp)
+    p64, s64, lo64 = sp_opt(sp_build(cfg, zero_rows).double(), d(X), d(coords), d(t), d(y), sp)
+    out["opt_losses32"], out["opt_losses64"] = lo32, lo64
+    for k in p64:
+        store(out, "p", k, p64[k].numpy(), p32[k].numpy(), cfg["seed"] + 7, False)
+        store(out, "ema", k, s64[k].numpy(), s32[k].numpy(), cfg["seed"] + 7, False)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB  loss64={out['loss64']:.6f} "
+          f"pen=({out['spatial_penalty64']:.5f}, {out['temporal_penalty64']:.5f})")
+
+
 def gen_init_known_answers():
     """Knot tables of the reference's gmm / random_site initialisers (st_interp.py:187-343) on fixed
     points with a fixed global numpy seed."""
@@ -433,7 +510,7 @@ def gen_init_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["knots", "model", "n3", "n2", "init"]
+    which = sys.argv[1:] or ["knots", "model", "n3", "n2", "init", "sparsity"]
     if "init" in which:
         gen_init_known_answers()
     if "n2" in which:
@@ -444,6 +521,9 @@ if __name__ == "__main__":
     if "model" in which:
         for nm in cases.MODEL_CASES:
             gen_case(nm)
+    if "sparsity" in which:
+        for name in cases.SPARSITY_CASES:
+            gen_sparsity_case(name)
     if "n3" in which:
         import scripts.train_st_interp as ref_train  # noqa: E402  (the reference's loss functions)
         gen_n3_known_answers()

@@ -346,3 +346,59 @@ def test_n2_oracle_optimizer_steps(name):
     for k in params:
         _digest_check(params[k], g, "p", k, cfg["seed"] + 7, 1e-8)
         _digest_check(shadow[k], g, "ema", k, cfg["seed"] + 7, 1e-8)
+
+
+# ------------------------------------------------------------------ sparsity penalties on the first layer
+def _sparsity_step(X, coords, t, y, params, cfg, sp):
+    """MSE + the applied penalties and their gradient (train_st_interp.py:617-621,674-693)."""
+    yp, loss, grads = orc.train_step_grads(X, coords, t, y, params, cfg)
+    k0 = next(iter(params))
+    ps, pt, dW = orc.sparsity_penalty(params[k0], cfg["p"], sum(cfg["k_spatial_centers"]),
+                                      sum(cfg["k_temporal_centers"]), sp["kind"], sp["lambda_l1"],
+                                      sp["lambda_group"], sp.get("apply_spatial", True),
+                                      sp.get("apply_temporal", True))
+    loss += (ps if sp.get("apply_spatial", True) else 0.0) + (pt if sp.get("apply_temporal", True) else 0.0)
+    grads = dict(grads)
+    grads[k0] = grads[k0] + dW
+    return loss, ps, pt, grads
+
+
+@pytest.mark.parametrize("name", list(cases.SPARSITY_CASES))
+def test_sparsity_oracle_matches_reference_float64(name):
+    cfg, sp, zero_rows = cases.sparsity_cfg(name)
+    g = load(name)
+    X, coords, t, y = cases.make_inputs(cfg)
+    params = {k: v.astype(np.float64) for k, v in cases.sparsity_state(cfg, zero_rows).items()}
+    loss, ps, pt, grads = _sparsity_step(X, coords, t, y, params, cfg, sp)
+    assert abs(ps - float(g["spatial_penalty64"])) < 1e-11 and abs(pt - float(g["temporal_penalty64"])) < 1e-11
+    assert abs(loss - float(g["loss64"])) < 1e-10
+    for k in params:
+        _digest_check(grads[k], g, "g", k, cfg["seed"] + 7, 1e-9)
+
+
+@pytest.mark.parametrize("name", list(cases.SPARSITY_CASES))
+def test_sparsity_oracle_optimizer_steps(name):
+    cfg, sp, zero_rows = cases.sparsity_cfg(name)
+    g = load(name)
+    o = cases.OPT
+    X, coords, t, y = cases.make_inputs(cfg)
+    params = {k: v.astype(np.float64) for k, v in cases.sparsity_state(cfg, zero_rows).items()}
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v2 = {k: np.zeros_like(v) for k, v in params.items()}
+    shadow = {k: v.copy() for k, v in params.items()}
+    losses = []
+    for s in range(1, o["steps"] + 1):
+        loss, _, _, grads = _sparsity_step(X, coords, t, y, params, cfg, sp)
+        losses.append(loss)
+        orc.adamw_ema_step(params, grads, m, v2, shadow, s, o["lr"], o["weight_decay"], o["betas"],
+                           o["eps"], o["grad_clip"], o["ema_decay"])
+    assert np.abs(np.array(losses) - g["opt_losses64"]).max() < 1e-8
+    for k in params:
+        _digest_check(params[k], g, "p", k, cfg["seed"] + 7, 1e-8)
+        _digest_check(shadow[k], g, "ema", k, cfg["seed"] + 7, 1e-8)
+
+
+def test_sparsity_oracle_rejects_unknown_kind():
+    with pytest.raises(ValueError):
+        orc.sparsity_penalty(np.zeros((2, 3)), 0, 2, 1, "lasso")
+    assert orc.sparsity_penalty(np.ones((2, 3)), 0, 2, 1, "none")[:2] == (0.0, 0.0)
