@@ -368,6 +368,9 @@ def main():
                 "learnable_knots": timed(B, 30, dict(spatial_learnable=True, gradient_damping=True,
                                                      damping_threshold=0.0, damping_strength=5.0),
                                          dict(domain_penalty_weight=0.01)),
+                # sparse-group lasso on the first layer (train_st_interp.py:674-691)
+                "sparse_group_penalty": timed(B, 60, None, dict(sparsity_penalty_type="sparse_group",
+                                                                sparsity_lambda_l1=1e-4, sparsity_lambda_group=1e-3)),
             }
             # the reference's SHIPPED YAML (configs/*.yaml: 227 GMM-initialised learnable knots, 5 quantiles
             # with the delta-free head, batch 4096): scattered knots => materialising kernels

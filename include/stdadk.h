@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STDADK_ABI_VERSION 3
+#define STDADK_ABI_VERSION 4
 #define STDADK_MAX_HIDDEN 8
 #define STDADK_MAX_LEVELS 8
 #define STDADK_SUMSQ_PARTS 256 /* partial sums written by stdadk_sumsq_f32 */
@@ -341,6 +341,32 @@ int stdadk_train_fwd_bwd_indexed_f32(const stdadk_basis_desc *basis, const stdad
                                      void *workspace, size_t workspace_bytes, uint64_t drop_seed,
                                      const int32_t *step_dev, int32_t flags, stdadk_stream_t stream,
                                      stdadk_stream_t aux_stream);
+
+/* Sparsity penalties on the first Linear's weights: STInterpMLP.compute_sparsity_penalty /
+ * _compute_penalty_for_block (stnf/models/st_interp.py:724-825) as the batch body adds them to the loss
+ * before loss.backward() (scripts/train_st_interp.py:674-691).  A basis function's group is its row of
+ * W0^T (w0_t = 1: W0 stored (D, H0), the engine's layout) or its column of W0 (w0_t = 0: (H0, D), the
+ * nn.Linear layout); the p covariate rows carry no penalty (:763-765).
+ *   ELEMENT       lambda_l1 * sum |w|
+ *   GROUP         lambda_group * sum over basis functions of ||w_j||_2
+ *   SPARSE_GROUP  both
+ * dW0 += grad_scale * d(applied penalties)/dW0 with torch's sub-gradients (sign(0) = 0; an all-zero group has
+ * gradient 0); loss_sum += loss_scale * (applied penalties); penalties[0] += spatial, penalties[1] += temporal
+ * value (reported whether applied or not, like the reference's dict).  dW0, loss_sum, penalties may be NULL. */
+#define STDADK_SPARSITY_NONE 0
+#define STDADK_SPARSITY_ELEMENT 1
+#define STDADK_SPARSITY_GROUP 2
+#define STDADK_SPARSITY_SPARSE_GROUP 3
+typedef struct {
+  int32_t kind;            /* STDADK_SPARSITY_*                                             */
+  float lambda_l1;         /* sparsity_lambda_l1                                            */
+  float lambda_group;      /* sparsity_lambda_group                                         */
+  int32_t apply_spatial;   /* sparsity_apply_to_spatial  (train_st_interp.py:679,688)       */
+  int32_t apply_temporal;  /* sparsity_apply_to_temporal (train_st_interp.py:680,690)       */
+} stdadk_sparsity_desc;
+int stdadk_sparsity_f32(const stdadk_sparsity_desc *s, const float *W0, float *dW0, int64_t ld,
+                        int32_t w0_t, int32_t H0, int32_t p, int32_t Ks, int32_t Kt, float grad_scale,
+                        float loss_scale, float *loss_sum, float *penalties, stdadk_stream_t stream);
 
 /* A0 + A2-A9 in ONE call (single GPU): stdadk_train_fwd_bwd(_indexed)_f32, then clip_grad_norm_ +
  * AdamW + EMA (stdadk_sumsq_f32 + stdadk_adamw_ema_f32) on the flat buffers of `opt`, whose gradient

@@ -38,7 +38,7 @@ class BasisDesc(C.Structure):
                 ("t_bw", C.c_void_p)]
 
 
-ABI_VERSION = 3            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
+ABI_VERSION = 4            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
 MAX_Q = 8
 LOSS_MSE, LOSS_PINBALL = 0, 1
 
@@ -62,6 +62,14 @@ class AdamGroup(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_float), ("lr_dev", C.c_void_p), ("max_norm", C.c_float),
                 ("sumsq_parts", C.c_void_p), ("n_parts", C.c_int32)]
+
+
+SPARSITY_KINDS = {"none": 0, "element": 1, "group": 2, "sparse_group": 3}
+
+
+class SparsityDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lambda_l1", C.c_float), ("lambda_group", C.c_float),
+                ("apply_spatial", C.c_int32), ("apply_temporal", C.c_int32)]
 
 
 class KnotTrain(C.Structure):
@@ -103,6 +111,9 @@ _SIGNATURES = {
     "stdadk_delta_head_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                  C.c_int32, C.c_int32, C.c_float, C.c_float,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stdadk_sparsity_f32": (C.c_int, [C.POINTER(SparsityDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "stdadk_train_step_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
                                         C.POINTER(MlpTensors), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_float, C.POINTER(LossDesc), C.c_void_p,
@@ -414,6 +425,32 @@ def delta_head_backward(delta, dWo, dbo, lambda_grad, lambda_loss, d_delta, loss
                                               lambda_grad, lambda_loss, gptr, _dev(loss_sum, "loss_sum"),
                                               _stream())
     _check(rc, "stdadk_delta_head_backward_f32")
+
+
+def make_sparsity(kind, lambda_l1=0.01, lambda_group=0.01, apply_spatial=True, apply_temporal=True):
+    if kind not in SPARSITY_KINDS:
+        raise ValueError(f"Unknown penalty_type: {kind}")
+    s = SparsityDesc()
+    s.kind, s.lambda_l1, s.lambda_group = SPARSITY_KINDS[kind], float(lambda_l1), float(lambda_group)
+    s.apply_spatial, s.apply_temporal = int(bool(apply_spatial)), int(bool(apply_temporal))
+    return s
+
+
+def sparsity(sp, W0, dW0, w0_t, p, Ks, Kt, grad_scale=1.0, loss_scale=0.0, loss_sum=None, penalties=None):
+    """stdadk_sparsity_f32: W0 / dW0 are (D, H0) with w0_t, else (H0, D); penalties (2,) accumulates
+    (spatial, temporal)."""
+    D = p + Ks + Kt
+    H0 = W0.shape[1] if w0_t else W0.shape[0]
+    if tuple(W0.shape) != ((D, H0) if w0_t else (H0, D)):
+        raise RuntimeError(f"sparsity: W0 has shape {tuple(W0.shape)}, D = {D}")
+    if dW0 is not None and (dW0.shape != W0.shape or dW0.stride() != W0.stride()):
+        raise RuntimeError("sparsity: dW0 must have the shape and strides of W0")
+    if penalties is not None and penalties.numel() != 2:
+        raise RuntimeError("sparsity: penalties must hold 2 floats")
+    rc = lib().stdadk_sparsity_f32(C.byref(sp), _dev(W0, "W0"), _dev(dW0, "dW0"), W0.stride(0), int(bool(w0_t)),
+                                   H0, p, Ks, Kt, grad_scale, loss_scale, _dev(loss_sum, "loss_sum"),
+                                   _dev(penalties, "penalties"), _stream())
+    _check(rc, "stdadk_sparsity_f32")
 
 
 def train_fwd_bwd(basis, desc, params, grads, coords, t, X, y, B, grad_scale, loss_sum, y_pred,

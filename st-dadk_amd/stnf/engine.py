@@ -103,6 +103,9 @@ class TrainStep:
     `domain_penalty_weight` / `movement_penalty_weight` add the penalties of st_interp.py:493-546 to the
     objective, and the model's gradient-damping settings apply to the centres' gradient.
 
+    Sparsity penalties on the first layer (`sparsity_penalty_type` 'element' | 'group' | 'sparse_group' with the
+    config keys of scripts/train_st_interp.py:674-691): value into the loss accumulator, gradient into dW0.
+
     Launch mode: an eager chain of kernels by default (`use_graph=True` replays it from a hipGraph);
     `step_indexed(..., next_idx=...)` / `run_epoch` overlap the next batch's preparation with the step."""
 
@@ -111,7 +114,9 @@ class TrainStep:
                  process_group=None, distributed=None, force_dense=False, two_streams=False,
                  loss="mse", quantile_levels=None, non_crossing_weight=0.0, non_crossing_power=1,
                  non_crossing_lambda=0.0, basis_lr_ratio=0.05, basis_clip_ratio=0.1,
-                 domain_penalty_weight=0.0, movement_penalty_weight=0.0):
+                 domain_penalty_weight=0.0, movement_penalty_weight=0.0, sparsity_penalty_type="none",
+                 sparsity_lambda_l1=0.001, sparsity_lambda_group=0.01, sparsity_apply_to_spatial=True,
+                 sparsity_apply_to_temporal=True):
         self.model = model
         if loss not in ("mse", "pinball"):
             raise ValueError(f"unknown loss '{loss}'; use 'mse' or 'pinball'")
@@ -157,6 +162,15 @@ class TrainStep:
                 else:
                     views.append(self.grad[o:o + k].view(p.shape))
         self.grad_views = views
+        # sparsity penalties on the first layer (config keys of train_st_interp.py:674-691): their gradient
+        # is added to dW0^T by stdadk_sparsity_f32 between backward and clipping
+        self._sparsity = None
+        if sparsity_penalty_type != "none":
+            self._sparsity = N.make_sparsity(sparsity_penalty_type, sparsity_lambda_l1, sparsity_lambda_group,
+                                             sparsity_apply_to_spatial, sparsity_apply_to_temporal)
+            o, k = by_name[next(n for n, p in model.named_parameters() if p is first_w)]
+            self._w0t = self.flat[o:o + k].view(first_w.shape[1], first_w.shape[0])
+            self._g_w0t = self.grad[o:o + k].view(first_w.shape[1], first_w.shape[0])
         # learnable knots (DA-STDK): their own AdamW group (lr x basis_lr_ratio) and clip norm
         # (grad_clip x basis_clip_ratio), scripts/train_st_interp.py:470-483,698-705; the knot tensors
         # are registered first, so they occupy the head [0, knot_end) of the flat buffers
@@ -214,7 +228,7 @@ class TrainStep:
         # the one-call step applies with a single parameter group on one GPU (data-parallel training needs
         # the all-reduce between backward and optimiser; learnable knots / the delta head have extra kernels there)
         self._whole_step = (not self.distributed and not self.learnable and not model._has_delta
-                            and self.aux_stream is None)
+                            and self.aux_stream is None and self._sparsity is None)
         self._optim = None
         self._sumsq512 = torch.zeros(N.GRADSQ_PARTS, device=self.dev)
         self._pipe = None          # two workspaces + side stream of the pipelined batch preparation
@@ -278,6 +292,10 @@ class TrainStep:
                                    penalty_grad_scale=1.0 / self.world, penalty_loss_scale=float(B * Q))
             N.knot_backward(st.basis, st.desc, st.params, coords, B, ws, st.flags, kt,
                             self.g_centers, self.g_log_bw, self.loss_sum)
+        if self._sparsity is not None:
+            m = self.model
+            N.sparsity(self._sparsity, self._w0t, self._g_w0t, True, m.p, m.k_spatial, m.k_temporal,
+                       grad_scale=1.0 / self.world, loss_scale=float(B * Q), loss_sum=self.loss_sum)
         if self.distributed:
             D.allreduce_gradients(self.grad, self.pg)
         ke = self.knot_end

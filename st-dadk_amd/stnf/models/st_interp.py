@@ -246,6 +246,30 @@ class _StepFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
+class _SparsityFunction(torch.autograd.Function):
+    """(spatial, temporal) sparsity penalties of the first Linear's weight through stdadk_sparsity_f32."""
+
+    @staticmethod
+    def forward(ctx, w, p, Ks, Kt, kind, l1, lg):
+        ctx.save_for_backward(w)
+        ctx.cfg = (p, Ks, Kt, kind, l1, lg)
+        pen = torch.zeros(2, device=w.device)
+        wc = w.detach().contiguous()
+        N.sparsity(N.make_sparsity(kind, l1, lg), wc, None, False, p, Ks, Kt, penalties=pen)
+        return pen[0].clone(), pen[1].clone()
+
+    @staticmethod
+    def backward(ctx, gs, gt):
+        (w,) = ctx.saved_tensors
+        p, Ks, Kt, kind, l1, lg = ctx.cfg
+        wc = w.detach().contiguous()
+        dW = torch.zeros_like(wc)
+        N.sparsity(N.make_sparsity(kind, l1, lg), wc, dW, False, p, Ks, Kt)      # unit gradient of both blocks
+        dW[:, p:p + Ks] *= gs
+        dW[:, p + Ks:p + Ks + Kt] *= gt
+        return dW, None, None, None, None, None, None
+
+
 class _StepState:
     """ABI descriptors for one forward/backward pair (keeps the tensors they point to alive)."""
     __slots__ = ("basis", "desc", "params", "flags", "w0_transposed", "keep", "delta", "head")
@@ -450,8 +474,9 @@ class STInterpMLP(nn.Module):
         return list(self.delta_params)
 
     def compute_sparsity_penalty(self, penalty_type='element', lambda_l1=0.01, lambda_group=0.01):
-        """L1 / group-lasso penalties on the first layer's basis columns (reference :724-825);
-        host-side torch on the (256, D) weight, differentiable."""
+        """L1 / group-lasso penalties on the first layer's basis columns (reference :724-825), differentiable:
+        stdadk_sparsity_f32 for value and gradient on the device.  Inside the fused engine the same kernel adds
+        the gradient straight into dW0 (TrainStep(sparsity_penalty_type=...))."""
         if penalty_type not in ['element', 'group', 'sparse_group', 'none']:
             raise ValueError(f"Unknown penalty_type: {penalty_type}")
         dev = next(self.parameters()).device
@@ -459,6 +484,11 @@ class STInterpMLP(nn.Module):
             z = torch.tensor(0.0, device=dev)
             return {'spatial_penalty': z, 'temporal_penalty': z.clone(), 'total_penalty': z.clone()}
         w = self._body[0].weight
+        if w.is_cuda:
+            ps, pt = _SparsityFunction.apply(w, self.p, self.k_spatial, self.k_temporal, penalty_type,
+                                             float(lambda_l1), float(lambda_group))
+            return {'spatial_penalty': ps, 'temporal_penalty': pt, 'total_penalty': ps + pt}
+        # parameters still on the host (model not yet moved to the device): nothing for the library to do
         blocks = (w[:, self.p:self.p + self.k_spatial],
                   w[:, self.p + self.k_spatial:self.p + self.k_spatial + self.k_temporal])
         pens = []

@@ -1472,3 +1472,114 @@ def test_launch_fusions_are_bitwise_neutral(switch, monkeypatch):
         res.append(eng.flat.clone())
     monkeypatch.delenv(switch, raising=False)
     assert torch.equal(res[0], res[1])
+
+
+# ------------------------------------------------------------------ sparsity penalties on the first layer
+def build_sparsity_model(name):
+    cfg, sp, zero_rows = cases.sparsity_cfg(name)
+    m = build_model(cfg)
+    with torch.no_grad():
+        w = m._body[0].weight
+        for r in zero_rows:
+            w[:, cfg["p"] + r] = 0.0
+    return m, cfg, sp, zero_rows
+
+
+@pytest.mark.parametrize("w0_t", [True, False])
+@pytest.mark.parametrize("kind,H,p,Ks,Kt,ap_s,ap_t", [
+    ("element", 32, 0, 9, 5, True, True), ("group", 256, 3, 227, 70, True, False),
+    ("sparse_group", 256, 0, 1031, 70, True, True), ("sparse_group", 128, 2, 70, 9, False, True),
+    ("group", 48, 1, 5, 0, True, True), ("sparse_group", 30, 1, 9, 5, True, True)])
+def test_sparsity_kernel_matches_oracle(kind, H, p, Ks, Kt, ap_s, ap_t, w0_t):
+    """stdadk_sparsity_f32 in both weight layouts: penalty values, gradient added INTO dW0 (with its scale),
+    the loss accumulator; zero weights and an all-zero group take torch's sub-gradient 0; covariate
+    columns untouched."""
+    from stnf import _native as N
+    rs = np.random.RandomState(H + Ks + Kt)
+    D = p + Ks + Kt
+    W = rs.standard_normal((H, D)).astype(np.float32) * 0.1
+    W[:, p + 1] = 0.0                    # an all-zero group
+    W[rs.randint(0, H, 40), rs.randint(p, D, 40)] = 0.0
+    G0 = rs.standard_normal((H, D)).astype(np.float32)
+    l1, lg, gs, ls = 0.013, 0.021, 0.5, 7.0
+    ps, pt, dW = orc.sparsity_penalty(W, p, Ks, Kt, kind, l1, lg, ap_s, ap_t)
+    d = dev()
+    Wd = torch.from_numpy(W.T.copy() if w0_t else W).to(d)
+    Gd = torch.from_numpy(G0.T.copy() if w0_t else G0.copy()).to(d)
+    loss = torch.full((1,), 2.0, device=d)
+    pen = torch.zeros(2, device=d)
+    N.sparsity(N.make_sparsity(kind, l1, lg, ap_s, ap_t), Wd, Gd, w0_t, p, Ks, Kt, grad_scale=gs, loss_scale=ls,
+               loss_sum=loss, penalties=pen)
+    got = Gd.cpu().numpy().astype(np.float64)
+    got = got.T if w0_t else got
+    assert np.abs(got - (G0 + gs * dW)).max() <= 2e-6
+    assert np.array_equal(got[:, :p], G0[:, :p].astype(np.float64))
+    assert abs(pen[0].item() - ps) <= 1e-5 * max(1.0, ps) and abs(pen[1].item() - pt) <= 1e-5 * max(1.0, pt)
+    applied = (ps if ap_s else 0.0) + (pt if ap_t else 0.0)
+    assert abs(loss.item() - (2.0 + ls * applied)) <= 1e-5 * max(1.0, ls * applied)
+    # values only (no gradient buffer), and kind 'none' is a no-op
+    pen.zero_()
+    N.sparsity(N.make_sparsity(kind, l1, lg, ap_s, ap_t), Wd, None, w0_t, p, Ks, Kt, penalties=pen)
+    assert abs(pen[0].item() - ps) <= 1e-5 * max(1.0, ps)
+    before = Gd.clone()
+    N.sparsity(N.make_sparsity("none"), Wd, Gd, w0_t, p, Ks, Kt, penalties=pen)
+    assert torch.equal(before, Gd)
+    with pytest.raises(ValueError):
+        N.make_sparsity("lasso")
+
+
+@pytest.mark.parametrize("name", list(cases.SPARSITY_CASES))
+def test_sparsity_module_loop_matches_reference(name):
+    """The batch body written on the drop-in module: MSE + compute_sparsity_penalty terms, backward
+    (train_st_interp.py:617-621,674-693) -- loss, penalties and every gradient against the float64 golden."""
+    m, cfg, sp, _ = build_sparsity_model(name)
+    g = load(name)
+    d = dev()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    m.train()
+    loss = torch.nn.MSELoss()(m(X if cfg["p"] else None, coords, t), y)
+    pen = m.compute_sparsity_penalty(penalty_type=sp["kind"], lambda_l1=sp["lambda_l1"],
+                                     lambda_group=sp["lambda_group"])
+    if sp.get("apply_spatial", True):
+        loss = loss + pen["spatial_penalty"]
+    if sp.get("apply_temporal", True):
+        loss = loss + pen["temporal_penalty"]
+    loss.backward()
+    assert abs(pen["spatial_penalty"].item() - float(g["spatial_penalty64"])) <= 1e-5 * max(1.0, float(g["spatial_penalty64"]))
+    assert abs(pen["temporal_penalty"].item() - float(g["temporal_penalty64"])) <= 1e-5 * max(1.0, float(g["temporal_penalty64"]))
+    assert abs(pen["total_penalty"].item() - float(g["spatial_penalty64"]) - float(g["temporal_penalty64"])) <= 2e-5 * max(1.0, float(g["spatial_penalty64"]))
+    assert abs(loss.item() - float(g["loss64"])) <= 2e-5 * max(1.0, float(g["loss64"]))
+    for k, p in m.named_parameters():
+        check_vs_digest(p.grad.cpu().numpy(), g, "g", k, cfg["seed"] + 7, tol=2e-5)
+
+
+@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("name", list(cases.SPARSITY_CASES))
+def test_sparsity_engine_steps_match_reference(name, dense):
+    """OPT['steps'] fused steps with the sparsity gradient added between backward and clipping."""
+    from stnf.engine import TrainStep
+    m, cfg, sp, _ = build_sparsity_model(name)
+    g = load(name)
+    o = cases.OPT
+    d = dev()
+    m.train()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    eng = TrainStep(m, lr=o["lr"], weight_decay=o["weight_decay"], betas=o["betas"], eps=o["eps"],
+                    grad_clip=o["grad_clip"], ema_decay=o["ema_decay"], max_batch=cfg["B"], force_dense=dense,
+                    sparsity_penalty_type=sp["kind"], sparsity_lambda_l1=sp["lambda_l1"],
+                    sparsity_lambda_group=sp["lambda_group"],
+                    sparsity_apply_to_spatial=sp.get("apply_spatial", True),
+                    sparsity_apply_to_temporal=sp.get("apply_temporal", True))
+    assert not eng._whole_step
+    losses = []
+    for _ in range(o["steps"]):
+        eng.step(X if cfg["p"] else None, coords, t, y)
+        losses.append(eng.mean_loss())
+    ref = g["opt_losses64"]
+    assert np.abs(np.array(losses) - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), (losses, ref)
+    for k, p in m.named_parameters():
+        check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=1e-4)
+    eng.swap_in_ema()
+    for k, p in m.named_parameters():
+        check_vs_digest(p.detach().cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=1e-4)
+    eng.swap_in_ema()

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(handle, sym), f"{sym} declared in stdadk.h but not exported"
     assert declared == set(N.exported_symbols()), declared ^ set(N.exported_symbols())
-    assert N.lib().stdadk_abi_version() == 3
+    assert N.lib().stdadk_abi_version() == N.ABI_VERSION == 4
 
 
 def test_abi_struct_layout_matches_header():
@@ -241,6 +241,7 @@ def test_n3_host_surface():
     assert ctypes.sizeof(N.AdamGroup) == 88 and N.AdamGroup.lr_dev.offset == 56 and N.AdamGroup.n_parts.offset == 80
     # stdadk_optim_desc: 5 pointers, int64, float (+pad), pointer, 4 floats, pointer, float (+pad), pointer, float (+pad)
     assert ctypes.sizeof(N.OptimDesc) == 112 and N.OptimDesc.step_dev.offset == 80 and N.OptimDesc.sumsq_parts.offset == 96
+    assert ctypes.sizeof(N.SparsityDesc) == 20 and N.SparsityDesc.apply_spatial.offset == 12
     # stdadk_knot_train: pointer, int32, 6 floats (+pad to 8)
     assert ctypes.sizeof(N.KnotTrain) == 40
     ld = N.make_loss("pinball", 3, 1, [0.1, 0.5, 0.9], 0.5, 2)
