@@ -374,7 +374,9 @@ int stdadk_sparsity_f32(const stdadk_sparsity_desc *s, const float *W0, float *d
  * library take the gradient's squared norm out of the launches that produce it (window path: no
  * separate pass over the gradient); otherwise it runs the separate kernels.  idx may be NULL (rows
  * 0..B-1 of the given arrays).  opt->step_dev (device int32, required) is read by dropout and AdamW and
- * advanced once.  Data-parallel training keeps the split calls: the all-reduce sits between them. */
+ * advanced once.  `sparsity` (may be NULL): the first-layer penalties of stdadk_sparsity_f32, their
+ * gradient added before clipping and their value x B x Q into loss_sum, like the batch body does.
+ * Data-parallel training keeps the split calls: the all-reduce sits between them. */
 #define STDADK_GRADSQ_PARTS 512
 typedef struct stdadk_optim_desc {
   float *p, *g, *m, *v, *ema;   /* flat fp32 buffers of n elements; ema may be NULL                 */
@@ -391,8 +393,9 @@ int stdadk_train_step_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc 
                           const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,
                           const float *coords, const float *t, const float *X, const float *y,
                           const int64_t *idx, int64_t B, float grad_scale, const stdadk_loss_desc *loss,
-                          float *loss_sum, void *workspace, size_t workspace_bytes, uint64_t drop_seed,
-                          int32_t flags, const stdadk_optim_desc *opt, stdadk_stream_t stream);
+                          const stdadk_sparsity_desc *sparsity, float *loss_sum, void *workspace,
+                          size_t workspace_bytes, uint64_t drop_seed, int32_t flags,
+                          const stdadk_optim_desc *opt, stdadk_stream_t stream);
 
 /* A0, window path: the batch-preparation half of the step on its own — gathers rows idx[b] (NULL = rows
  * 0..B-1) of coords_all / t_all / X_all / y_all [N, y_cols] and bins them into `workspace`, exactly as

@@ -249,4 +249,246 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// R consecutive observations per wave (fixed grid knots).  The observations are cell-sorted, so neighbours in
+// the sorted order see almost the same knots: the candidates of a level are the bounding box of the R 6 x 6
+// windows (at most 8 x 8 = one per lane; a knot outside an observation's own window evaluates to exactly 0 for
+// it), a row of W0^T is fetched ONCE and feeds R accumulators, and so does a temporal row from LDS.  The L2
+// row-gather traffic per observation -- what the one-observation-per-wave body is bound by -- drops to the
+// size of the union over R.  Every observation still sums its own non-zero knots in the same order (level by
+// level, ix-major), and fmaf(0, w, acc) == acc, so the result is bit-identical to R = 1.  When the windows of a
+// group are too far apart for one 8 x 8 box (wrap-around of the cell order), the chunk of levels is done one
+// observation at a time.
+template <int CPL, bool LN, int BASIS, int R>
+__device__ __forceinline__ void l1_window_fwd_multi_body(const L1FwdArgs &a, float *smem, const int r0, const int r1) {
+  constexpr int H = 64 * CPL;
+  constexpr int NW = FW_T / 64;
+  const int Kt = a.g.Kt;
+  const int Kt_pad = (Kt + 3) & ~3;
+  float *Wt = smem;                                          // [Kt][H] temporal rows of W0^T
+  float *lphi = Wt + (size_t)Kt * H;                         // [NW][LIST][R]
+  int *lk = reinterpret_cast<int *>(lphi + NW * LIST * R);   // [NW][LIST]
+  float *lpsi = reinterpret_cast<float *>(lk + NW * LIST);   // [NW][Kt_pad][R]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D0 = a.g.p + a.g.Ks;
+  const int rowf = r0 + R * wave;
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(a.W0T + (size_t)D0 * H);
+    float4 *dst = reinterpret_cast<float4 *>(Wt);
+    for (int i = tid; i < Kt * H / 4; i += FW_T) dst[i] = src[i];
+  }
+  __syncthreads();
+  float *my_phi = lphi + wave * LIST * R;
+  int *my_k = lk + wave * LIST;
+  float *my_psi = lpsi + wave * Kt_pad * R;
+  const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint64_t below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+  const int bdx = lane >> 3, bdy = lane & 7;              // this lane's place in an 8 x 8 candidate box
+
+  for (int row = rowf; row < r1; row += R * NW) {
+    const int nv = min(R, r1 - row);                      // observations of this group (the rest repeat the last)
+    float x[R], y[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = row + min(r, nv - 1);
+      x[r] = a.xs[i]; y[r] = a.ys[i];
+    }
+    float acc[R][CPL];
+    {
+      const typename VecT<CPL>::T bv = *reinterpret_cast<const typename VecT<CPL>::T *>(a.b0 + CPL * lane);
+      const float *bf = reinterpret_cast<const float *>(&bv);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[r][c] = bf[c];
+    }
+
+    // gather-FMA of the first `cnt` list entries (cnt a multiple of 8): NF rows of W0^T in flight, R uses of each
+    constexpr int NF = 8;
+    auto consume = [&](int cnt) {
+      for (int e0 = 0; e0 < cnt; e0 += NF) {
+        unsigned ro[NF];
+#pragma unroll
+        for (int e = 0; e < NF; ++e) ro[e] = (unsigned)my_k[e0 + e] * (unsigned)H + (unsigned)(CPL * lane);
+        typename VecT<CPL>::T wv[NF];
+#pragma unroll
+        for (int e = 0; e < NF; ++e) wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(a.W0T + (size_t)ro[e]);
+#pragma unroll
+        for (int e = 0; e < NF; ++e) {
+          const float *f = reinterpret_cast<const float *>(&wv[e]);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float pv = my_phi[(e0 + e) * R + r];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[r][c] = fmaf(pv, f[c], acc[r][c]);
+          }
+        }
+      }
+    };
+    auto flush = [&](int n) {                             // zero-pad to a multiple of 8 and consume
+      const int npad = (n + 7) & ~7;
+      if (lane < npad - n) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) my_phi[(n + lane) * R + r] = 0.f;
+        my_k[n + lane] = 0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      consume(npad);
+      __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int l0 = 0; l0 < a.g.n_levels; l0 += 3) {
+      const int l1 = min(l0 + 3, a.g.n_levels);
+      // bounding box of the R windows per level (wave-uniform)
+      int bx0[3], by0[3], sx[3], sy[3];
+      bool far = false;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        bx0[j] = by0[j] = 0; sx[j] = sy[j] = 0;
+        if (l0 + j < l1) {
+          const int side = a.g.side[l0 + j];
+          const int win = side < WIN ? side : WIN;
+          int mnx = 1 << 30, mny = 1 << 30, mxx = 0, mxy = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int ix0 = window_start(x[r], side, win), iy0 = window_start(y[r], side, win);
+            mnx = min(mnx, ix0); mxx = max(mxx, ix0); mny = min(mny, iy0); mxy = max(mxy, iy0);
+          }
+          bx0[j] = mnx; by0[j] = mny; sx[j] = mxx - mnx + win; sy[j] = mxy - mny + win;
+          far = far || sx[j] > 8 || sy[j] > 8;
+        }
+      }
+      const int npass = far ? nv : 1;
+      for (int pass = 0; pass < npass; ++pass) {
+        int n = 0;
+        int kk[3];
+        bool ok[3];
+        float kx[3], ky[3], kb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          kk[j] = 0; ok[j] = false;
+          if (l0 + j < l1) {
+            const int l = l0 + j;
+            const int side = a.g.side[l];
+            const int win = side < WIN ? side : WIN;
+            int ix0 = bx0[j], iy0 = by0[j], spx = sx[j], spy = sy[j];
+            if (far) {
+              float xp = x[0], yp = y[0];
+#pragma unroll
+              for (int r = 1; r < R; ++r) if (r == pass) { xp = x[r]; yp = y[r]; }
+              ix0 = window_start(xp, side, win); iy0 = window_start(yp, side, win); spx = spy = win;
+            }
+            ok[j] = bdx < spx && bdy < spy;
+            kk[j] = a.g.off[l] + (ok[j] ? (ix0 + bdx) * side + iy0 + bdy : 0);
+          }
+          kx[j] = a.g.centers[2 * kk[j]];
+          ky[j] = a.g.centers[2 * kk[j] + 1];
+          kb[j] = a.g.bw[kk[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (l0 + j < l1) {
+            float phi[R];
+            bool any = false;
+            const float sc = knot_scale(kb[j], a.g.cal);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              phi[r] = (ok[j] && (!far || r == pass)) ? phi_eval<BASIS>(x[r], y[r], kx[j], ky[j], sc) : 0.f;
+              any = any || phi[r] != 0.f;
+            }
+            const uint64_t mask = __ballot(any);
+            const int m = __popcll(mask);
+            if (n + m > LIST - 8 - WIN_MAX_P) { flush(n); n = 0; }     // wave-uniform
+            if (any) {
+              const int pos = n + __popcll(mask & below);
+#pragma unroll
+              for (int r = 0; r < R; ++r) my_phi[pos * R + r] = phi[r];
+              my_k[pos] = a.g.p + kk[j];
+            }
+            n += m;
+          }
+        }
+        if (l0 == 0 && a.g.p > 0) {            // covariate columns [0, p): dense, per observation
+          if (lane < a.g.p) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              my_phi[(n + lane) * R + r] =
+                  (!far || r == pass) ? a.Xs[(size_t)(row + min(r, nv - 1)) * a.g.p + lane] : 0.f;
+            my_k[n + lane] = lane;
+          }
+          n += a.g.p;
+        }
+        flush(n);
+      }
+    }
+
+    // ---- temporal basis: each LDS row feeds the R accumulators
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float tr = a.ts[row + min(r, nv - 1)];
+      for (int j = lane; j < Kt; j += 64) {
+        const float v = psi_eval(tr, a.g.t_centers[j], a.g.t_bw[j]);
+        my_psi[j * R + r] = v;
+        if (a.psi && r < nv) a.psi[(size_t)(row + r) * a.ld_psi + j] = v;
+      }
+      if (a.psi && r < nv)
+        for (int j = Kt + lane; j < a.ld_psi; j += 64) a.psi[(size_t)(row + r) * a.ld_psi + j] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < Kt; ++j) {
+      typename VecT<CPL>::T v = *reinterpret_cast<const typename VecT<CPL>::T *>(Wt + (size_t)j * H + CPL * lane);
+      const float *f = reinterpret_cast<const float *>(&v);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float s = my_psi[j * R + r];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[r][c] = fmaf(s, f[c], acc[r][c]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- LayerNorm -> ReLU -> Dropout, row by row
+    float gam[CPL], bet[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      gam[c] = LN ? a.gamma[CPL * lane + c] : 1.f;
+      bet[c] = LN ? a.beta[CPL * lane + c] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < nv) {
+        const int orow = row + r;
+        float mean = 0.f, rs = 1.f;
+        if (LN) {
+          float s = 0.f;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) s += acc[r][c];
+          mean = wave_sum(s) / (float)H;
+          float sq = 0.f;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) { float d = acc[r][c] - mean; sq += d * d; }
+          rs = 1.0f / sqrtf(wave_sum(sq) / (float)H + a.eps);
+          if (lane == 0 && a.rstd) a.rstd[orow] = rs;
+        }
+        typename VecT<CPL>::T o1, o2;
+        float *f1 = reinterpret_cast<float *>(&o1), *f2 = reinterpret_cast<float *>(&o2);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const float xh = LN ? (acc[r][c] - mean) * rs : acc[r][c];
+          const float u = LN ? fmaf(xh, gam[c], bet[c]) : xh;
+          float v = fmaxf(u, 0.f);
+          if (a.drop_p > 0.f) {
+            const bool keep = drop_keep(seed, 0, (int64_t)orow * H + CPL * lane + c, a.drop_p);
+            v = keep ? v * keep_scale : 0.f;
+          }
+          f1[c] = xh; f2[c] = v;
+        }
+        if (a.xhat) *reinterpret_cast<typename VecT<CPL>::T *>(a.xhat + (size_t)orow * H + CPL * lane) = o1;
+        *reinterpret_cast<typename VecT<CPL>::T *>(a.act + (size_t)orow * H + CPL * lane) = o2;
+      }
+    }
+  }
+}
+
 }  // namespace stdadk

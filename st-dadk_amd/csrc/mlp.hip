@@ -1316,19 +1316,30 @@ extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_ml
                                      const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
                                      const float *coords, const float *t, const float *X, const float *y,
                                      const int64_t *idx, int64_t B, float grad_scale,
-                                     const stdadk_loss_desc *loss, float *loss_sum, void *workspace,
-                                     size_t workspace_bytes, uint64_t drop_seed, int32_t flags,
-                                     const stdadk_optim_desc *o, stdadk_stream_t stream) {
+                                     const stdadk_loss_desc *loss, const stdadk_sparsity_desc *sparsity,
+                                     float *loss_sum, void *workspace, size_t workspace_bytes,
+                                     uint64_t drop_seed, int32_t flags, const stdadk_optim_desc *o,
+                                     stdadk_stream_t stream) {
   STDADK_REQUIRE(o && o->p && o->g && o->m && o->v && o->n > 0 && o->step_dev, STDADK_E_ARG,
                  "train_step: optimiser descriptor incomplete");
   STDADK_REQUIRE(o->max_norm <= 0.f || o->sumsq_parts, STDADK_E_ARG, "train_step: max_norm > 0 needs sumsq_parts");
   if (B == 0) return 0;
   const bool clip = o->max_norm > 0.f;
+  const bool sparse = sparsity && sparsity->kind != STDADK_SPARSITY_NONE;
   bool sq_done = false;
+  // with a sparsity penalty the gradient changes once more after the reductions: the norm is a pass of its own
+  const bool fuse_sq = clip && !sparse;
   int rc = train_fwd_bwd_impl(b, d, P, G, coords, t, X, y, idx, B, grad_scale, loss, loss_sum, nullptr, workspace,
                               workspace_bytes, drop_seed, o->step_dev, flags, stream, nullptr,
-                              clip ? o->sumsq_parts : nullptr, clip ? o->step_dev : nullptr, &sq_done);
+                              fuse_sq ? o->sumsq_parts : nullptr, fuse_sq ? o->step_dev : nullptr, &sq_done);
   if (rc) return rc;
+  if (sparse) {
+    const bool w0_t = (flags & STDADK_FLAG_W0_T) != 0;
+    rc = stdadk_sparsity_f32(sparsity, P->W[0], G->W[0], w0_t ? d->hidden[0] : d->in_dim, w0_t, d->hidden[0],
+                             b->p, (int32_t)b->Ks, (int32_t)b->Kt, 1.0f, (float)B * (float)d->out_dim, loss_sum,
+                             nullptr, stream);
+    if (rc) return rc;
+  }
   int n_parts = 0;
   if (clip && sq_done) {
     n_parts = STDADK_GRADSQ_PARTS;                 // partials (and the step advance) came out of the reductions launch

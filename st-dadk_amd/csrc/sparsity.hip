@@ -2,6 +2,7 @@
 // L1, group lasso per basis function, or both -- penalty value and its (sub-)gradient added to dW0.
 // A basis function's group is its row of W0^T (D, H0) resp. its column of W0 (H0, D).  Streaming work:
 // one read of W0 and one read-modify-write of dW0.
+#include <algorithm>
 #include "common.h"
 #include "../../include/stdadk.h"
 
@@ -23,15 +24,16 @@ struct SparsityArgs {
 
 __device__ __forceinline__ float sgn(float w) { return w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f); }
 
-// block-level sums of the two penalties, then one atomic each
+// block-level sums of the two penalties, then one atomic each.  Adds to ONE address serialise at the memory
+// side (measured: ~12 ns each), so the launches below keep the number of workgroups in the low hundreds.
 __device__ __forceinline__ void publish(const SparsityArgs &a, float pen_s, float pen_t) {
-  __shared__ float red[2][4];
+  __shared__ float red[2][16];
   const float s = wave_sum(pen_s), t = wave_sum(pen_t);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = t; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float ps = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    const float pt = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    float ps = 0.f, pt = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ps += red[0][w]; pt += red[1][w]; }
     if (a.pen) {
       if (ps != 0.f) atomicAdd(a.pen, ps);
       if (pt != 0.f) atomicAdd(a.pen + 1, pt);
@@ -41,64 +43,89 @@ __device__ __forceinline__ void publish(const SparsityArgs &a, float pen_s, floa
   }
 }
 
-// W0^T layout (D, H0): one wave per basis row (contiguous), 4 rows per 256-thread workgroup.  VEC: H0 is a
-// multiple of 4 and at most 1024, rows 16-byte aligned: the row sits in registers (one or a few float4 per
-// lane) between the norm and the gradient, and the gradient row is requested before the reduction.
-template <bool VEC>
-__global__ void __launch_bounds__(256) sparsity_rows_kernel(SparsityArgs a) {
+constexpr int ROWS_T = 1024;   // one 16-wave workgroup per CU
+
+// W0^T layout (D, H0): one wave per basis row (contiguous), grid-stride over the rows.  NV > 0: H0 is a multiple
+// of 4 and at most 256 * NV, rows 16-byte aligned: a row sits in registers (NV float4 per lane) between the norm
+// and the gradient, and the NEXT row of the wave (weights and gradient) is requested before the current one is
+// reduced, so a wave always has a row in flight.  NV = 0: any H0, scalar accesses.
+template <int NV>
+__global__ void __launch_bounds__(ROWS_T) sparsity_rows_kernel(SparsityArgs a) {
+  constexpr int WPB = ROWS_T / 64;                        // rows (waves) per workgroup and pass
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);     // basis function
+  const int n = a.n_s + a.n_t, stride = gridDim.x * WPB;
   float pen_s = 0.f, pen_t = 0.f;
-  if (j < a.n_s + a.n_t) {
-    const bool temporal = j >= a.n_s;
-    const bool apply = temporal ? a.apply_t : a.apply_s;
-    if (apply || a.pen) {
-      const float *w = a.W + (int64_t)(a.row0 + j) * a.ld;
-      float *g = a.dW ? a.dW + (int64_t)(a.row0 + j) * a.ld : nullptr;
-      const bool grad = apply && g != nullptr;
+  const bool want_pen = a.pen != nullptr;
+  if constexpr (NV > 0) {
+    const int nv = a.H >> 2;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 x[NV], gv[NV], xn[NV], gn[NV];
+    auto fetch = [&](int j, float4 *xo, float4 *go) {
+      const bool temporal = j >= a.n_s;
+      const bool apply = temporal ? a.apply_t : a.apply_s;
+      const float4 *w = reinterpret_cast<const float4 *>(a.W + (int64_t)(a.row0 + j) * a.ld);
+      const float4 *g = reinterpret_cast<const float4 *>(a.dW + (int64_t)(a.row0 + j) * a.ld);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        xo[k] = (i < nv && (apply || want_pen)) ? w[i] : zero;
+        go[k] = (i < nv && apply && a.dW) ? g[i] : zero;
+      }
+    };
+    int j = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (j < n) fetch(j, x, gv);
+    for (; j < n; j += stride) {
+      const int jn = j + stride;
+      if (jn < n) fetch(jn, xn, gn);
+      const bool temporal = j >= a.n_s;
+      const bool apply = temporal ? a.apply_t : a.apply_s;
       float sq = 0.f, ab = 0.f;
-      if constexpr (VEC) {
-        float4 x[4], gv[4];
-        const int nv = a.H >> 2;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NV; ++k) {
+        sq += x[k].x * x[k].x + x[k].y * x[k].y + x[k].z * x[k].z + x[k].w * x[k].w;
+        ab += fabsf(x[k].x) + fabsf(x[k].y) + fabsf(x[k].z) + fabsf(x[k].w);
+      }
+      sq = wave_sum(sq); ab = wave_sum(ab);
+      const float nrm = sqrtf(sq);
+      if (lane == 0 && (apply || want_pen)) {
+        const float pen = a.l1 * ab + a.lg * nrm;
+        if (temporal) pen_t += pen; else pen_s += pen;
+      }
+      if (apply && a.dW) {
+        float4 *g = reinterpret_cast<float4 *>(a.dW + (int64_t)(a.row0 + j) * a.ld);
+        const float inv = nrm > 0.f ? a.lg / nrm : 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
           const int i = lane + 64 * k;
-          x[k] = i < nv ? reinterpret_cast<const float4 *>(w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-          if (grad && i < nv) gv[k] = reinterpret_cast<const float4 *>(g)[i];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          sq += x[k].x * x[k].x + x[k].y * x[k].y + x[k].z * x[k].z + x[k].w * x[k].w;
-          ab += fabsf(x[k].x) + fabsf(x[k].y) + fabsf(x[k].z) + fabsf(x[k].w);
-        }
-        sq = wave_sum(sq); ab = wave_sum(ab);
-        const float nrm = sqrtf(sq);
-        if (lane == 0) { const float pen = a.l1 * ab + a.lg * nrm; if (temporal) pen_t = pen; else pen_s = pen; }
-        if (grad) {
-          const float inv = nrm > 0.f ? a.lg / nrm : 0.f;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int i = lane + 64 * k;
-            if (i < nv) {
-              gv[k].x += a.gscale * (a.l1 * sgn(x[k].x) + inv * x[k].x);
-              gv[k].y += a.gscale * (a.l1 * sgn(x[k].y) + inv * x[k].y);
-              gv[k].z += a.gscale * (a.l1 * sgn(x[k].z) + inv * x[k].z);
-              gv[k].w += a.gscale * (a.l1 * sgn(x[k].w) + inv * x[k].w);
-              reinterpret_cast<float4 *>(g)[i] = gv[k];
-            }
+          if (i < nv) {
+            gv[k].x += a.gscale * (a.l1 * sgn(x[k].x) + inv * x[k].x);
+            gv[k].y += a.gscale * (a.l1 * sgn(x[k].y) + inv * x[k].y);
+            gv[k].z += a.gscale * (a.l1 * sgn(x[k].z) + inv * x[k].z);
+            gv[k].w += a.gscale * (a.l1 * sgn(x[k].w) + inv * x[k].w);
+            g[i] = gv[k];
           }
         }
-      } else {
-        for (int i = lane; i < a.H; i += 64) { const float x = w[i]; sq += x * x; ab += fabsf(x); }
-        sq = wave_sum(sq); ab = wave_sum(ab);
-        const float nrm = sqrtf(sq);
-        if (lane == 0) { const float pen = a.l1 * ab + a.lg * nrm; if (temporal) pen_t = pen; else pen_s = pen; }
-        if (grad) {
-          const float inv = nrm > 0.f ? a.lg / nrm : 0.f;
-          for (int i = lane; i < a.H; i += 64) {
-            const float x = w[i];
-            g[i] += a.gscale * (a.l1 * sgn(x) + inv * x);
-          }
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) { x[k] = xn[k]; gv[k] = gn[k]; }
+    }
+  } else {
+    for (int j = blockIdx.x * WPB + (threadIdx.x >> 6); j < n; j += stride) {
+      const bool temporal = j >= a.n_s;
+      const bool apply = temporal ? a.apply_t : a.apply_s;
+      if (!(apply || want_pen)) continue;
+      const float *w = a.W + (int64_t)(a.row0 + j) * a.ld;
+      float sq = 0.f, ab = 0.f;
+      for (int i = lane; i < a.H; i += 64) { const float v = w[i]; sq += v * v; ab += fabsf(v); }
+      sq = wave_sum(sq); ab = wave_sum(ab);
+      const float nrm = sqrtf(sq);
+      if (lane == 0) { const float pen = a.l1 * ab + a.lg * nrm; if (temporal) pen_t += pen; else pen_s += pen; }
+      if (apply && a.dW) {
+        float *g = a.dW + (int64_t)(a.row0 + j) * a.ld;
+        const float inv = nrm > 0.f ? a.lg / nrm : 0.f;
+        for (int i = lane; i < a.H; i += 64) {
+          const float v = w[i];
+          g[i] += a.gscale * (a.l1 * sgn(v) + inv * v);
         }
       }
     }
@@ -164,11 +191,16 @@ extern "C" int stdadk_sparsity_f32(const stdadk_sparsity_desc *s, const float *W
   if (!penalties && !a.apply_s && !a.apply_t) return 0;
   const int n = Ks + Kt;
   if (w0_t) {
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n, ROWS_T / 64), 256);
     const bool vec = (H0 & 3) == 0 && H0 <= 1024 && (ld & 3) == 0 && aligned16(W0) && (!dW0 || aligned16(dW0));
-    if (vec) {
-      STDADK_LAUNCH(sparsity_rows_kernel<true>, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    if (vec && H0 <= 256) {
+      STDADK_LAUNCH(sparsity_rows_kernel<1>, dim3(grid), dim3(ROWS_T), 0, (hipStream_t)stream, a);
+    } else if (vec && H0 <= 512) {
+      STDADK_LAUNCH(sparsity_rows_kernel<2>, dim3(grid), dim3(ROWS_T), 0, (hipStream_t)stream, a);
+    } else if (vec) {
+      STDADK_LAUNCH(sparsity_rows_kernel<4>, dim3(grid), dim3(ROWS_T), 0, (hipStream_t)stream, a);
     } else {
-      STDADK_LAUNCH(sparsity_rows_kernel<false>, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, a);
+      STDADK_LAUNCH(sparsity_rows_kernel<0>, dim3(grid), dim3(ROWS_T), 0, (hipStream_t)stream, a);
     }
   } else {
     STDADK_LAUNCH(sparsity_cols_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, (hipStream_t)stream, a);

@@ -319,11 +319,13 @@ int unpermute_rows(const float *in, const int *perm, int B, int Q, float *out, h
 // ---------------------------------------------------------------------------------------------
 // forward:  z0 -> LayerNorm -> ReLU -> Dropout, one wave per observation
 // ---------------------------------------------------------------------------------------------
-template <int CPL, bool LN, int BASIS, bool FREE>
+// R: observations per wave (1: l1_window_fwd_body; 2: l1_window_fwd_multi_body, fixed knots only)
+template <int CPL, bool LN, int BASIS, bool FREE, int R>
 __global__ __launch_bounds__(FW_T) void l1_window_fwd_kernel(L1FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int r0 = l1_chunk_of(blockIdx.x, a.n_wg) * a.rows_per_wg;
-  l1_window_fwd_body<CPL, LN, BASIS, FREE>(a, smem, r0, min(r0 + a.rows_per_wg, a.B));
+  if constexpr (R == 1) l1_window_fwd_body<CPL, LN, BASIS, FREE>(a, smem, r0, min(r0 + a.rows_per_wg, a.B));
+  else l1_window_fwd_multi_body<CPL, LN, BASIS, R>(a, smem, r0, min(r0 + a.rows_per_wg, a.B));
 }
 
 // HALO_SPLIT workgroups per level: each takes a slice of the level's knots and writes the slice's
@@ -374,11 +376,11 @@ bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt) {
   return true;
 }
 
-template <int CPL, bool LN, int BASIS, bool FREE>
+template <int CPL, bool LN, int BASIS, bool FREE, int R>
 static int launch_fwd_t(const L1FwdArgs &a, hipStream_t st) {
   const int Kt_pad = (a.g.Kt + 3) & ~3;
-  size_t lds = ((size_t)a.g.Kt * 64 * CPL + (FW_T / 64) * (LIST * 2 + Kt_pad)) * sizeof(float);
-  auto kern = l1_window_fwd_kernel<CPL, LN, BASIS, FREE>;
+  size_t lds = ((size_t)a.g.Kt * 64 * CPL + (FW_T / 64) * (LIST * (R + 1) + Kt_pad * R)) * sizeof(float);
+  auto kern = l1_window_fwd_kernel<CPL, LN, BASIS, FREE, R>;
   // raise the dynamic-LDS cap when a launch needs more than any before it (never inside a stream
   // capture: the engine runs its first step eagerly)
   static size_t attr_lds = 0;
@@ -393,9 +395,25 @@ static int launch_fwd_t(const L1FwdArgs &a, hipStream_t st) {
   return 0;
 }
 
+// observations per wave: 2 once every wave of a workgroup still gets a full group (measured on MI355X, C2
+// model: 4 per wave is no faster than 2 -- the union of four windows needs the registers that keep 8 rows in
+// flight -- and 2 per wave is +14..17 % on forward-only calls of 65 536+ rows, +2..5 % on train steps of
+// 8 192+).  Environment STDADK_L1_GROUP = 1 | 2 overrides (diagnostic).
+static int l1_group(const L1FwdArgs &a) {
+  if (a.halo) return 1;
+  int r = a.rows_per_wg >= 2 * (FW_T / 64) ? 2 : 1;
+  if (const char *e = getenv("STDADK_L1_GROUP")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2) r = v;
+  }
+  return r;
+}
+
 template <int CPL, bool LN, int BASIS>
 static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
-  return a.halo ? launch_fwd_t<CPL, LN, BASIS, true>(a, st) : launch_fwd_t<CPL, LN, BASIS, false>(a, st);
+  if (a.halo) return launch_fwd_t<CPL, LN, BASIS, true, 1>(a, st);
+  return l1_group(a) == 2 ? launch_fwd_t<CPL, LN, BASIS, false, 2>(a, st)
+                          : launch_fwd_t<CPL, LN, BASIS, false, 1>(a, st);
 }
 
 int l1_window_forward(const L1FwdArgs &a_in, int basis, bool ln, hipStream_t st) {

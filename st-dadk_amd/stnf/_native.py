@@ -116,9 +116,9 @@ _SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "stdadk_train_step_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
                                         C.POINTER(MlpTensors), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_int64, C.c_float, C.POINTER(LossDesc), C.c_void_p,
-                                        C.c_void_p, C.c_size_t, C.c_uint64, C.c_int32, C.POINTER(OptimDesc),
-                                        C.c_void_p]),
+                                        C.c_void_p, C.c_int64, C.c_float, C.POINTER(LossDesc),
+                                        C.POINTER(SparsityDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
+                                        C.c_int32, C.POINTER(OptimDesc), C.c_void_p]),
     "stdadk_sumsq2_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "stdadk_adamw_ema2_f32": (C.c_int, [C.POINTER(AdamGroup), C.POINTER(AdamGroup), C.c_float, C.c_float,
@@ -606,14 +606,16 @@ def make_optim(p, g, m, v, ema, lr, lr_dev, betas, eps, weight_decay, step_dev, 
 
 
 def train_step(basis, desc, params, grads, coords, t, X, y, idx, B, grad_scale, loss_sum, workspace, flags, optim,
-               seed=0, loss_desc=None):
-    """The whole single-GPU step in one call: forward, objective, backward, clip + AdamW + EMA."""
+               seed=0, loss_desc=None, sparsity_desc=None):
+    """The whole single-GPU step in one call: forward, objective (+ first-layer sparsity penalties), backward,
+    clip + AdamW + EMA."""
     if idx is not None and (idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous()):
         raise RuntimeError("train_step: idx must be a contiguous int64 tensor on the device")
     rc = lib().stdadk_train_step_f32(
         C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads), _dev(coords, "coords"), _dev(t, "t"),
         _dev(X, "X"), _dev(y, "y"), idx.data_ptr() if idx is not None else None, B, grad_scale,
-        C.byref(loss_desc) if loss_desc is not None else None, _dev(loss_sum, "loss_sum"), workspace.data_ptr(),
+        C.byref(loss_desc) if loss_desc is not None else None,
+        C.byref(sparsity_desc) if sparsity_desc is not None else None, _dev(loss_sum, "loss_sum"), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), seed, flags, C.byref(optim), _stream())
     _check(rc, "stdadk_train_step_f32")
 

@@ -228,7 +228,7 @@ class TrainStep:
         # the one-call step applies with a single parameter group on one GPU (data-parallel training needs
         # the all-reduce between backward and optimiser; learnable knots / the delta head have extra kernels there)
         self._whole_step = (not self.distributed and not self.learnable and not model._has_delta
-                            and self.aux_stream is None and self._sparsity is None)
+                            and self.aux_stream is None)
         self._optim = None
         self._sumsq512 = torch.zeros(N.GRADSQ_PARTS, device=self.dev)
         self._pipe = None          # two workspaces + side stream of the pipelined batch preparation
@@ -264,7 +264,8 @@ class TrainStep:
                                            self._sumsq512 if self.grad_clip > 0 else None, self.ema_decay)
             N.train_step(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y,
                          idx if not prebinned else None, B, D.grad_scale(global_rows, Q), self.loss_sum, ws, flags,
-                         self._optim, seed=self.seed, loss_desc=self._loss_desc(y.shape[1]))
+                         self._optim, seed=self.seed, loss_desc=self._loss_desc(y.shape[1]),
+                         sparsity_desc=self._sparsity)
             return
         if st.head is not None:
             N.delta_head(st.delta, st.head[0], st.head[1])          # output layer of this step's delta

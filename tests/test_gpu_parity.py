@@ -1489,7 +1489,8 @@ def build_sparsity_model(name):
 @pytest.mark.parametrize("kind,H,p,Ks,Kt,ap_s,ap_t", [
     ("element", 32, 0, 9, 5, True, True), ("group", 256, 3, 227, 70, True, False),
     ("sparse_group", 256, 0, 1031, 70, True, True), ("sparse_group", 128, 2, 70, 9, False, True),
-    ("group", 48, 1, 5, 0, True, True), ("sparse_group", 30, 1, 9, 5, True, True)])
+    ("group", 48, 1, 5, 0, True, True), ("sparse_group", 30, 1, 9, 5, True, True),
+    ("sparse_group", 512, 0, 300, 9, True, True), ("element", 1024, 1, 40, 7, True, True)])
 def test_sparsity_kernel_matches_oracle(kind, H, p, Ks, Kt, ap_s, ap_t, w0_t):
     """stdadk_sparsity_f32 in both weight layouts: penalty values, gradient added INTO dW0 (with its scale),
     the loss accumulator; zero weights and an all-zero group take torch's sub-gradient 0; covariate
@@ -1553,10 +1554,11 @@ def test_sparsity_module_loop_matches_reference(name):
         check_vs_digest(p.grad.cpu().numpy(), g, "g", k, cfg["seed"] + 7, tol=2e-5)
 
 
-@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("dense,whole", [(False, True), (True, True), (False, False)])
 @pytest.mark.parametrize("name", list(cases.SPARSITY_CASES))
-def test_sparsity_engine_steps_match_reference(name, dense):
-    """OPT['steps'] fused steps with the sparsity gradient added between backward and clipping."""
+def test_sparsity_engine_steps_match_reference(name, dense, whole):
+    """OPT['steps'] fused steps with the sparsity gradient added between backward and clipping, through the
+    one-call step entry and through the split calls."""
     from stnf.engine import TrainStep
     m, cfg, sp, _ = build_sparsity_model(name)
     g = load(name)
@@ -1570,7 +1572,8 @@ def test_sparsity_engine_steps_match_reference(name, dense):
                     sparsity_lambda_group=sp["lambda_group"],
                     sparsity_apply_to_spatial=sp.get("apply_spatial", True),
                     sparsity_apply_to_temporal=sp.get("apply_temporal", True))
-    assert not eng._whole_step
+    assert eng._whole_step
+    eng._whole_step = whole
     losses = []
     for _ in range(o["steps"]):
         eng.step(X if cfg["p"] else None, coords, t, y)
@@ -1583,3 +1586,40 @@ def test_sparsity_engine_steps_match_reference(name, dense):
     for k, p in m.named_parameters():
         check_vs_digest(p.detach().cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=1e-4)
     eng.swap_in_ema()
+
+
+@pytest.mark.parametrize("name", ["tiny9_ln_p3", "default227", "default227_tri", "c2_b257", "c2_b257_noln"])
+def test_layer0_observation_groups_are_bit_identical(name, monkeypatch):
+    """Layer-0 window forward with 2 cell-adjacent observations per wave (one fetch of a W0^T row feeds
+    both; the default for large batches) against one observation per wave: every observation sums its
+    own knots in the same order, so outputs and gradients are bit-identical -- including ragged groups at the
+    end of a workgroup's rows and groups whose windows are too far apart to share a candidate box."""
+    cfg = cases.MODEL_CASES[name]
+    d = dev()
+    X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+    # more rows than the golden batch (an odd count: a ragged last group), a clustered half so that many groups share knots
+    rs = np.random.RandomState(5)
+    n = 1003
+    c2 = torch.from_numpy(np.concatenate([rs.uniform(0, 1, (n // 2, 2)), 0.4 + 0.02 * rs.standard_normal((n - n // 2, 2))])
+                          .astype(np.float32)).to(d)
+    t2 = torch.from_numpy(rs.uniform(0, 1, (n, 1)).astype(np.float32)).to(d)
+    X2 = torch.from_numpy(rs.standard_normal((n, cfg["p"])).astype(np.float32)).to(d) if cfg["p"] else None
+    y2 = torch.from_numpy(rs.standard_normal((n, 1)).astype(np.float32)).to(d)
+    res = {}
+    for grp in ("1", "2"):
+        monkeypatch.setenv("STDADK_L1_GROUP", grp)
+        m = build_model(cfg, dropout=0.1)
+        m.eval()
+        with torch.no_grad():
+            ye = m(X2, c2, t2).clone()
+        m.train()
+        torch.manual_seed(11)                 # the module draws its dropout seed from torch's generator
+        out = m(X2, c2, t2)
+        torch.nn.functional.mse_loss(out, y2).backward()
+        res[grp] = (ye, out.detach().clone(), [p.grad.clone() for p in m.parameters()])
+    monkeypatch.delenv("STDADK_L1_GROUP", raising=False)
+    for grp in ("2",):
+        assert torch.equal(res[grp][0], res["1"][0]), grp
+        assert torch.equal(res[grp][1], res["1"][1]), grp
+        for ga, gb in zip(res[grp][2], res["1"][2]):
+            assert torch.equal(ga, gb), grp
