@@ -11,11 +11,13 @@ namespace stdadk {
 
 static_assert(GT == BW_T, "the GEMM tiles and the knot groups must share the workgroup shape");
 
-template <int CPL, int BASIS, bool KNOTS>
+// NK (fixed knots only): 2 neighbouring knots per wave, see l1_window_bwd_multi_body; 1: one knot per wave
+template <int CPL, int BASIS, bool KNOTS, int NK>
 __global__ __launch_bounds__(GT) void dw_all_kernel(GemmGroup grp, int n_gemm_blocks, L1BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[TileGeom<64, true>::SIZE * 2];
   // GEMM tiles take the low block ids (dispatched first): measured 33.5 us vs 42.5 us the other way round
   if ((int)blockIdx.x < n_gemm_blocks) gemm_tn_grouped_block(grp, (int)blockIdx.x, lds);
+  else if constexpr (NK > 1) l1_window_bwd_multi_body<CPL, BASIS, NK>(a, (int)blockIdx.x - n_gemm_blocks);
   else l1_window_bwd_body<CPL, BASIS, KNOTS>(a, (int)blockIdx.x - n_gemm_blocks);
 }
 
@@ -26,13 +28,16 @@ int launch_dw_all(GemmGroup &grp, const L1BwdArgs &a, int basis, hipStream_t st)
   int ng = 0;
   int rc = gemm_tn_grouped_prepare(grp, &ng);
   if (rc) return rc;
-  const unsigned grid = (unsigned)ng + (unsigned)ceil_div(a.g.Ks, BW_T / 64);
+  const int nk = knots_per_wave(a);
+  const unsigned grid = (unsigned)ng + (unsigned)ceil_div(knot_group_count(a.g, nk), BW_T / 64);
 #define GO(CPL_, BS_)                                                                                      \
   do {                                                                                                     \
-    if (a.kpart) STDADK_LAUNCH_NAMED("dw_all_kernel<knots>", (dw_all_kernel<CPL_, BS_, true>), dim3(grid), \
-                                     dim3(GT), 0, st, grp, ng, a);                                         \
-    else STDADK_LAUNCH_NAMED("dw_all_kernel", (dw_all_kernel<CPL_, BS_, false>), dim3(grid), dim3(GT), 0,  \
-                             st, grp, ng, a);                                                              \
+    if (a.kpart) STDADK_LAUNCH_NAMED("dw_all_kernel<knots>", (dw_all_kernel<CPL_, BS_, true, 1>),          \
+                                     dim3(grid), dim3(GT), 0, st, grp, ng, a);                             \
+    else if (nk == 2) STDADK_LAUNCH_NAMED("dw_all_kernel", (dw_all_kernel<CPL_, BS_, false, 2>), dim3(grid), \
+                                          dim3(GT), 0, st, grp, ng, a);                                    \
+    else STDADK_LAUNCH_NAMED("dw_all_kernel", (dw_all_kernel<CPL_, BS_, false, 1>), dim3(grid),            \
+                             dim3(GT), 0, st, grp, ng, a);                                                 \
   } while (0)
   if (a.H == 256) { if (basis == STDADK_BASIS_WENDLAND) GO(4, 0); else GO(4, 2); }
   else if (a.H == 128) { if (basis == STDADK_BASIS_WENDLAND) GO(2, 0); else GO(2, 2); }

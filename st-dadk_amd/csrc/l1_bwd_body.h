@@ -187,4 +187,172 @@ __device__ __forceinline__ void l1_window_bwd_body(const L1BwdArgs &a, const int
   *reinterpret_cast<typename VecT<CPL>::T *>(a.dW0T + (size_t)(a.g.p + k) * H + CPL * lane) = o;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// NK = 2 or 4 neighbouring knots per wave (fixed grid knots): knots (ix, iy), (ix, iy + 1) [and (ix + 1, iy),
+// (ix + 1, iy + 1)] of a level see almost the same observations (supports of 5 spacings, one spacing apart), so
+// the candidates are walked once over the union of the supports, a dZ row is fetched once and feeds all NK
+// accumulators.  Every knot still sums its own non-zero observations in sorted order and fmaf(0, dz, acc) == acc,
+// so the rows of dW0^T are bit-identical to the one-knot-per-wave body.  Groups: level by level, ceil(side / 2)
+// pairs per grid row (NK = 2) or ceil(side / 2)^2 blocks of 2 x 2 (NK = 4); knots past the edge of an odd grid
+// are absent.  knot_group_count() in window.hip counts the groups for the launch.
+template <int CPL, int BASIS, int NK>
+__device__ __forceinline__ void l1_window_bwd_multi_body(const L1BwdArgs &a, const int block) {
+  constexpr int H = 64 * CPL;
+  constexpr int NX = NK / 2;                          // knots along ix
+  __shared__ float lphi[BW_T / 64][NK][BW_LIST + 8];
+  __shared__ int lidx[BW_T / 64][BW_LIST + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int q = block * (BW_T / 64) + wave;                 // group index, level by level
+  int l = 0;
+  for (; l < a.g.n_levels; ++l) {
+    const int hp = (a.g.side[l] + 1) >> 1;
+    const int np = (NX == 2 ? hp : a.g.side[l]) * hp;
+    if (q < np) break;
+    q -= np;
+  }
+  if (l >= a.g.n_levels) return;
+  const int side = a.g.side[l], hp = (side + 1) >> 1;
+  const int gx = q / hp, ix = NX * gx, iy = 2 * (q - gx * hp);
+  int kk[NK];
+  bool has[NK];
+  float kx[NK], ky[NK], ksc[NK];
+  float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const int dx = j >> 1, dy = j & 1;
+    has[j] = ix + dx < side && iy + dy < side;
+    kk[j] = a.g.off[l] + (has[j] ? (ix + dx) * side + iy + dy : ix * side + iy);
+    kx[j] = a.g.centers[2 * kk[j]]; ky[j] = a.g.centers[2 * kk[j] + 1];
+    const float bw = a.g.bw[kk[j]];
+    ksc[j] = knot_scale(bw, a.g.cal);
+    const float r = bw * a.g.cal;                     // support radius
+    xlo = fminf(xlo, kx[j] - r); xhi = fmaxf(xhi, kx[j] + r);
+    ylo = fminf(ylo, ky[j] - r); yhi = fmaxf(yhi, ky[j] + r);
+  }
+  int *my_idx = lidx[wave];
+  const int G = a.G;
+  // cells overlapping any of the support squares, one cell of margin against rounding
+  const int cx_lo = max(floor_clamp(xlo * (float)G, G) - 1, 0);
+  const int cx_hi = min(floor_clamp(xhi * (float)G, G) + 1, G - 1);
+  const int cy_lo = max(floor_clamp(ylo * (float)G, G) - 1, 0);
+  const int cy_hi = min(floor_clamp(yhi * (float)G, G) + 1, G - 1);
+  const uint64_t below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+
+  float acc[NK][CPL];
+#pragma unroll
+  for (int j = 0; j < NK; ++j)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[j][c] = 0.f;
+  int n = 0;
+
+  auto flush = [&](int cnt) {     // cnt is a multiple of 8
+    for (int e0 = 0; e0 < cnt; e0 += 8) {
+      typename VecT<CPL>::T wv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(
+            a.dZ + (size_t)((unsigned)my_idx[e0 + e] * (unsigned)H + (unsigned)(CPL * lane)));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float *f = reinterpret_cast<const float *>(&wv[e]);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+          const float pv = lphi[wave][j][e0 + e];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[j][c] = fmaf(pv, f[c], acc[j][c]);
+        }
+      }
+    }
+  };
+
+  for (int cxb = cx_lo; cxb <= cx_hi; cxb += 64) {
+    const int cxl = cxb + lane;
+    int seg0 = 0, seg1 = 0;
+    if (cxl <= cx_hi) { seg0 = a.cell_start[cxl * G + cy_lo]; seg1 = a.cell_start[cxl * G + cy_hi + 1]; }
+    int incl = seg1 - seg0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    const int total = __shfl(incl, 63, 64);
+    for (int f0 = 0; f0 < total; f0 += 64) {
+      const int f = f0 + lane;
+      int lo = 0;
+#pragma unroll
+      for (int st = 32; st > 0; st >>= 1) {
+        const int probe = __shfl(incl, lo + st - 1, 64);
+        if (probe <= f) lo += st;
+      }
+      const int jl = lo < 63 ? lo : 63;
+      const int pin = __shfl(incl, jl, 64);
+      const int pl = __shfl(seg1 - seg0, jl, 64);
+      const int ps0 = __shfl(seg0, jl, 64);
+      const int i = ps0 + (f - (pin - pl));
+      float pv[NK];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) pv[j] = 0.f;
+      if (f < total) {
+        const float x = a.xs[i], y = a.ys[i];
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+          pv[j] = has[j] ? phi_eval<BASIS>(x, y, kx[j], ky[j], ksc[j]) : 0.f;
+          any = any || pv[j] != 0.f;
+        }
+      }
+      const uint64_t mask = __ballot(any);
+      const int m = __popcll(mask);
+      if (n + m > BW_LIST) {      // not enough room: flush the full groups of 8, keep the remainder
+        __builtin_amdgcn_wave_barrier();
+        const int full = n & ~7;
+        flush(full);
+        __builtin_amdgcn_wave_barrier();
+        const int rem = n - full;
+        float tp[NK]; int ti = 0;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) tp[j] = 0.f;
+        if (lane < rem) {
+#pragma unroll
+          for (int j = 0; j < NK; ++j) tp[j] = lphi[wave][j][full + lane];
+          ti = my_idx[full + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rem) {
+#pragma unroll
+          for (int j = 0; j < NK; ++j) lphi[wave][j][lane] = tp[j];
+          my_idx[lane] = ti;
+        }
+        n = rem;
+      }
+      if (any) {
+        const int pos = n + __popcll(mask & below);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) lphi[wave][j][pos] = pv[j];
+        my_idx[pos] = i;
+      }
+      n += m;
+    }
+  }
+  const int npad = (n + 7) & ~7;
+  if (lane < npad - n) {
+#pragma unroll
+    for (int j = 0; j < NK; ++j) lphi[wave][j][n + lane] = 0.f;
+    my_idx[n + lane] = 0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  flush(npad);
+
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    if (has[j]) {
+      typename VecT<CPL>::T o;
+      float *fo = reinterpret_cast<float *>(&o);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) fo[c] = acc[j][c];
+      *reinterpret_cast<typename VecT<CPL>::T *>(a.dW0T + (size_t)(a.g.p + kk[j]) * H + CPL * lane) = o;
+    }
+  }
+}
+
 }  // namespace stdadk

@@ -65,6 +65,9 @@ struct L1FwdArgs {
 // z0 = [X|phi|psi] W0 + b0 -> LN -> ReLU -> Dropout for sorted observations; also writes psi.
 int l1_window_forward(const L1FwdArgs &a, int basis, bool layernorm, hipStream_t st);
 bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt);
+struct L1BwdArgs;
+int knot_group_count(const GridView &g, int nk);  // groups of the per-knot gather of dW0^T, nk knots per wave
+int knots_per_wave(const L1BwdArgs &a);
 
 struct L1BwdArgs {
   GridView g;

@@ -449,15 +449,49 @@ __global__ __launch_bounds__(BW_T) void l1_window_bwd_kernel(L1BwdArgs a) {
   l1_window_bwd_body<CPL, BASIS, KNOTS>(a, (int)blockIdx.x);
 }
 
+template <int CPL, int BASIS, int NK>
+__global__ __launch_bounds__(BW_T) void l1_window_bwd_multi_kernel(L1BwdArgs a) {
+  l1_window_bwd_multi_body<CPL, BASIS, NK>(a, (int)blockIdx.x);
+}
+
+// groups of the per-knot gather with nk knots per wave: level by level, ceil(side / 2) pairs per grid row
+// (nk = 2) or ceil(side / 2)^2 blocks of 2 x 2 (nk = 4)
+int knot_group_count(const GridView &g, int nk) {
+  if (nk <= 1) return g.Ks;
+  int n = 0;
+  for (int l = 0; l < g.n_levels; ++l) {
+    const int hp = (g.side[l] + 1) / 2;
+    n += (nk == 4 ? hp : g.side[l]) * hp;
+  }
+  return n;
+}
+
+// knots per wave of the per-knot gather: learnable knots 1; fixed grid knots 2 (environment
+// STDADK_KNOTS_PER_WAVE = 1 | 2 overrides, diagnostic).  Measured on MI355X, C2 model: 2 per wave is
+// -2.5 us on the merged weight-gradient launch at B = 4096 and -14 % on it at B = 65 536; blocks of 2 x 2
+// (the body supports NK = 4) are slower than pairs up to B = 16 384 and no faster at 65 536.
+int knots_per_wave(const L1BwdArgs &a) {
+  if (a.kpart) return 1;
+  int nk = 2;
+  if (const char *e = getenv("STDADK_KNOTS_PER_WAVE")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2) nk = v;
+  }
+  return nk;
+}
+
 int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st) {
   STDADK_REQUIRE(a.G <= 256, STDADK_E_ARG, "l1_window_backward: G too large");
   STDADK_REQUIRE((int64_t)a.B * a.H < (1ll << 32), STDADK_E_ARG, "l1_window_backward: B*H exceeds 32-bit offsets");
-  const unsigned grid = (unsigned)ceil_div(a.g.Ks, BW_T / 64);
+  const int nk = knots_per_wave(a);
+  const unsigned grid = (unsigned)ceil_div(knot_group_count(a.g, nk), BW_T / 64);
   STDADK_REQUIRE(!a.kpart || a.W0T, STDADK_E_ARG, "l1_window_backward: knot sums need W0^T");
 #define GO(CPL_, BS_)                                                                                        \
   do {                                                                                                       \
     if (a.kpart) STDADK_LAUNCH_NAMED("l1_window_bwd_kernel<knots>", (l1_window_bwd_kernel<CPL_, BS_, true>), \
                                      dim3(grid), dim3(BW_T), 0, st, a);                                      \
+    else if (nk == 2) STDADK_LAUNCH_NAMED("l1_window_bwd_kernel", (l1_window_bwd_multi_kernel<CPL_, BS_, 2>), \
+                                          dim3(grid), dim3(BW_T), 0, st, a);                                 \
     else STDADK_LAUNCH_NAMED("l1_window_bwd_kernel", (l1_window_bwd_kernel<CPL_, BS_, false>), dim3(grid),   \
                              dim3(BW_T), 0, st, a);                                                          \
   } while (0)

@@ -1623,3 +1623,37 @@ def test_layer0_observation_groups_are_bit_identical(name, monkeypatch):
         assert torch.equal(res[grp][1], res["1"][1]), grp
         for ga, gb in zip(res[grp][2], res["1"][2]):
             assert torch.equal(ga, gb), grp
+
+
+@pytest.mark.parametrize("name", ["default227", "default227_tri", "c2_b257", "c2_b257_noln"])
+def test_knot_groups_are_bit_identical(name, monkeypatch):
+    """Per-knot gather of dW0^T with two neighbouring knots per wave (one fetch of a dZ row feeds both; the
+    default for fixed knots) against one knot per wave: every knot sums its own observations in the same
+    order, so the gradients are bit-identical -- through the split backward (own kernel, module autograd) and
+    through the engine step (merged weight-gradient kernel); odd grid sides leave the last knot of a row alone."""
+    from stnf.engine import TrainStep
+    cfg = cases.MODEL_CASES[name]
+    d = dev()
+    rs = np.random.RandomState(6)
+    n = 1501
+    c2 = torch.from_numpy(np.concatenate([rs.uniform(-0.05, 1.05, (n // 2, 2)), 0.6 + 0.03 * rs.standard_normal((n - n // 2, 2))])
+                          .astype(np.float32)).to(d)
+    t2 = torch.from_numpy(rs.uniform(0, 1, (n, 1)).astype(np.float32)).to(d)
+    y2 = torch.from_numpy(rs.standard_normal((n, 1)).astype(np.float32)).to(d)
+    res = {}
+    for pairs in ("1", "2"):
+        monkeypatch.setenv("STDADK_KNOTS_PER_WAVE", pairs)
+        m = build_model(cfg)
+        m.train()
+        torch.nn.functional.mse_loss(m(None, c2, t2), y2).backward()
+        grads = [p.grad.clone() for p in m.parameters()]
+        m2 = build_model(cfg)
+        eng = TrainStep(m2, lr=1e-3, ema_decay=0.99, max_batch=n, grad_clip=0.0)
+        for _ in range(2):
+            eng.step(None, c2, t2, y2)
+        res[pairs] = (grads, eng.flat.clone())
+    monkeypatch.delenv("STDADK_KNOTS_PER_WAVE", raising=False)
+    for nk in ("2",):
+        for ga, gb in zip(res[nk][0], res["1"][0]):
+            assert torch.equal(ga, gb), nk
+        assert torch.equal(res[nk][1], res["1"][1]), nk
