@@ -84,9 +84,9 @@ __device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int blo
   if (n4 > 0) {
     p0 = reinterpret_cast<float4 *>(a.p)[jc];
     g0 = reinterpret_cast<const float4 *>(a.g)[jc];
-    m0 = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.m) + jc);
-    v0 = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.v) + jc);
-    if (a.ema) e0 = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.ema) + jc);
+    m0 = *(reinterpret_cast<nt4 *>(a.m) + jc);
+    v0 = *(reinterpret_cast<nt4 *>(a.v) + jc);
+    if (a.ema) e0 = *(reinterpret_cast<nt4 *>(a.ema) + jc);
   }
   const float lr = a.lr_dev ? a.lr_dev[0] : a.lr;
   const int step = a.step_dev ? a.step_dev[0] : a.step;
@@ -110,17 +110,19 @@ __device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int blo
   const float decay_mul = 1.f - lr * a.wd;
   int64_t done = 0;
   if (al) {
-    // m, v and the EMA shadow are pure streams (touched once per step): non-temporal accesses keep
-    // them from evicting the parameters and activations the next step wants in L2 / Infinity Cache
+    // m, v and the EMA shadow are pure streams (touched once per step): non-temporal STORES keep them from
+    // evicting the parameters and activations the next step wants in L2 / Infinity Cache (their loads are
+    // plain: measured 0.5-1 us faster than non-temporal loads, the 55 MB of optimiser state can sit in the
+    // 256 MB Infinity Cache from step to step)
     for (int64_t j = i0; j < n4; j += stride) {
       float4 p = p0, g = g0;
       nt4 mt = m0, vt = v0, et = e0;
       if (j != i0) {
         p = reinterpret_cast<float4 *>(a.p)[j];
         g = reinterpret_cast<const float4 *>(a.g)[j];
-        mt = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.m) + j);
-        vt = __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.v) + j);
-        et = a.ema ? __builtin_nontemporal_load(reinterpret_cast<nt4 *>(a.ema) + j) : (nt4){0, 0, 0, 0};
+        mt = *(reinterpret_cast<nt4 *>(a.m) + j);
+        vt = *(reinterpret_cast<nt4 *>(a.v) + j);
+        et = a.ema ? *(reinterpret_cast<nt4 *>(a.ema) + j) : (nt4){0, 0, 0, 0};
       }
       float4 m = make_float4(mt.x, mt.y, mt.z, mt.w), v = make_float4(vt.x, vt.y, vt.z, vt.w);
       float4 e = make_float4(et.x, et.y, et.z, et.w);

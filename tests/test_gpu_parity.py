@@ -1588,13 +1588,19 @@ def test_sparsity_engine_steps_match_reference(name, dense, whole):
     eng.swap_in_ema()
 
 
-@pytest.mark.parametrize("name", ["tiny9_ln_p3", "default227", "default227_tri", "c2_b257", "c2_b257_noln"])
+FOUR_LEVELS = dict(p=2, k_spatial_centers=[64, 144, 256, 400], k_temporal_centers=[10, 15], hidden_dims=[256, 128],
+                   layernorm=True, basis="wendland", output_dim=1, B=64, seed=71)
+
+
+@pytest.mark.parametrize("name", ["tiny9_ln_p3", "default227", "default227_tri", "c2_b257", "c2_b257_noln",
+                                  "four_levels_p2"])
 def test_layer0_observation_groups_are_bit_identical(name, monkeypatch):
     """Layer-0 window forward with 2 cell-adjacent observations per wave (one fetch of a W0^T row feeds
     both; the default for large batches) against one observation per wave: every observation sums its
     own knots in the same order, so outputs and gradients are bit-identical -- including ragged groups at the
-    end of a workgroup's rows and groups whose windows are too far apart to share a candidate box."""
-    cfg = cases.MODEL_CASES[name]
+    end of a workgroup's rows, groups whose windows are too far apart to share a candidate box, covariates and
+    a fourth level (a second chunk of levels)."""
+    cfg = cases.MODEL_CASES[name] if name in cases.MODEL_CASES else FOUR_LEVELS
     d = dev()
     X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
     # more rows than the golden batch (an odd count: a ragged last group), a clustered half so that many groups share knots
@@ -1625,14 +1631,14 @@ def test_layer0_observation_groups_are_bit_identical(name, monkeypatch):
             assert torch.equal(ga, gb), grp
 
 
-@pytest.mark.parametrize("name", ["default227", "default227_tri", "c2_b257", "c2_b257_noln"])
+@pytest.mark.parametrize("name", ["default227", "default227_tri", "c2_b257", "c2_b257_noln", "four_levels"])
 def test_knot_groups_are_bit_identical(name, monkeypatch):
     """Per-knot gather of dW0^T with two neighbouring knots per wave (one fetch of a dZ row feeds both; the
     default for fixed knots) against one knot per wave: every knot sums its own observations in the same
     order, so the gradients are bit-identical -- through the split backward (own kernel, module autograd) and
     through the engine step (merged weight-gradient kernel); odd grid sides leave the last knot of a row alone."""
     from stnf.engine import TrainStep
-    cfg = cases.MODEL_CASES[name]
+    cfg = cases.MODEL_CASES[name] if name in cases.MODEL_CASES else dict(FOUR_LEVELS, p=0)
     d = dev()
     rs = np.random.RandomState(6)
     n = 1501
