@@ -91,17 +91,28 @@ int launch_knot_grad(const KnotGradArgs &a, hipStream_t st) {
   return 0;
 }
 
-// per knot: fixed-order sum of the slab partials, + penalty gradients, x damping factor
+// per knot: fixed-order sum of the slab partials, + penalty gradients, x damping factor.  64 knots per
+// workgroup; its 4 waves each sum every 4th slab (independent loads), the four partial sums meet in LDS.
 __global__ __launch_bounds__(256) void knot_finish_kernel(KnotFinishArgs a) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  float pen = 0.f;
+  __shared__ float part[3][4][64];
+  __shared__ float red[4];
+  const int kl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kl;
+  float gx = 0.f, gy = 0.f, gl = 0.f;
   if (k < a.Ks) {
-    float gx = 0.f, gy = 0.f, gl = 0.f;
-    for (int s = 0; s < a.slabs; ++s) {
+    for (int s = sg; s < a.slabs; s += 4) {
       gx += a.part[((size_t)s * 3 + 0) * a.Ks + k];
       gy += a.part[((size_t)s * 3 + 1) * a.Ks + k];
       gl += a.part[((size_t)s * 3 + 2) * a.Ks + k];
     }
+  }
+  part[0][sg][kl] = gx; part[1][sg][kl] = gy; part[2][sg][kl] = gl;
+  __syncthreads();
+  float pen = 0.f;
+  if (sg == 0 && k < a.Ks) {
+    gx = (part[0][0][kl] + part[0][1][kl]) + (part[0][2][kl] + part[0][3][kl]);
+    gy = (part[1][0][kl] + part[1][1][kl]) + (part[1][2][kl] + part[1][3][kl]);
+    gl = (part[2][0][kl] + part[2][1][kl]) + (part[2][2][kl] + part[2][3][kl]);
     const float cx = a.centers[2 * k], cy = a.centers[2 * k + 1];
     float mx = 0.f, my = 0.f;
     if (a.centers_init) { mx = cx - a.centers_init[2 * k]; my = cy - a.centers_init[2 * k + 1]; }
@@ -127,7 +138,6 @@ __global__ __launch_bounds__(256) void knot_finish_kernel(KnotFinishArgs a) {
     a.d_log_bw[k] = gl;
   }
   if (a.loss_sum && a.pen_loss_scale != 0.f && (a.dom_w > 0.f || a.mov_w > 0.f)) {
-    __shared__ float red[4];
     const float s = wave_sum(pen);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(256) void knot_finish_kernel(KnotFinishArgs a) {
 }
 
 int launch_knot_finish(const KnotFinishArgs &a, hipStream_t st) {
-  STDADK_LAUNCH(knot_finish_kernel, dim3((unsigned)ceil_div(a.Ks, 256)), dim3(256), 0, st, a);
+  STDADK_LAUNCH(knot_finish_kernel, dim3((unsigned)ceil_div(a.Ks, 64)), dim3(256), 0, st, a);
   STDADK_CHECK_LAUNCH("knot_finish");
   return 0;
 }

@@ -100,6 +100,10 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
     if (mode == PLAN_STEP_WINDOW && d->n_hidden > 0) {
       grouped += job_floats(Kt, d->hidden[0]);
       if (p_cov > 0) grouped += job_floats(p_cov, d->hidden[0]);
+    } else if (d->n_hidden > 0) {
+      // materialising path, small D: dW0^T = features^T dZ_0 is a split-K product too and joins the group
+      int kps;
+      if (gemm_pick_splits(d->in_dim, d->hidden[0], (int)B, &kps, false) > 1) grouped += job_floats(d->in_dim, d->hidden[0]);
     }
     slab = grouped > slab ? grouped : slab;
   }
@@ -745,6 +749,20 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
       if (rc) return rc;
     }
     c.n_extra = 0;     // consumed
+    bool dw0_in_group = false;
+    if (layer0_dense && c.w0t) {
+      // materialising path with the (in,out) layout: while dW0^T = features^T dZ_0 is a split-K product
+      // (few tiles: small D) it joins the grouped launch and its slabs the grouped reduction -- two launches
+      // fewer than a stand-alone GEMM + slab sum; a D that fills the chip on its own keeps its direct GEMM
+      int kps;
+      const int h0 = d->hidden[0];
+      const int sp = gemm_pick_splits(d->in_dim, h0, (int)B, &kps, false);
+      if (sp > 1 && slab_off + (size_t)sp * d->in_dim * h0 <= pl.slab_floats) {
+        rc = add_tn(features, ldf, c.dz0, h0, d->in_dim, h0, G->W[0]);
+        if (rc) return rc;
+        dw0_in_group = true;
+      }
+    }
     if (c.merge_dw && !layer0_dense) {
       // window path: the caller issues these products together with the per-knot gather of dW0^T as one
       // launch, then the reductions (step_backward)
@@ -753,9 +771,15 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     }
     rc = launch_gemm_tn_grouped(gg, st);
     if (rc) return rc;
+    if (c.gradsq && c.all_grouped && layer0_dense && dw0_in_group && reduce_jobs_block_count(rg) <= 256) {
+      // one-call step: every gradient of the step is an output of this reductions launch, which then also
+      // leaves the squared-norm partials for the clip (no region beside them: sq_n = 0)
+      rg.sq_parts = c.gradsq; rg.sq_src = G->W[0]; rg.sq_n = 0; rg.step_inc = c.step_inc;
+      c.gradsq_done = true;
+    }
     rc = launch_reduce_jobs(rg, st);
     if (rc) return rc;
-    if (layer0_dense) {
+    if (layer0_dense && !dw0_in_group) {
       const int h = d->hidden[0];
       if (c.w0t)
         rc = gemm_run(features, ldf, true, c.dz0, h, true, d->in_dim, h, (int)B, nullptr, G->W[0], h, slab, false, nullptr, st);
