@@ -498,6 +498,9 @@ struct Ctx {
   bool l1_pend_valid = false;   // window path, B <= 4096: the layer-0 launch is parked as well
   L1FwdArgs l1_pend;
   int l1_basis = 0;
+  // materialising path, small D: layer 0 starts inside the tail launch from the raw observations (TailDense0)
+  bool d0 = false;
+  const float *d0_coords = nullptr, *d0_t = nullptr, *d0_X = nullptr, *d0_bw = nullptr;
   bool save = true;             // false in eval mode: the forward keeps nothing for a backward (xhat, rstd, act, psi)
   bool log_bw = false;          // basis->s_bw holds log-bandwidths (learnable knots)
   const int64_t *idx = nullptr; // window path: the batch is rows idx[b] of the resident observation arrays
@@ -609,12 +612,27 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
   STDADK_REQUIRE(P->W[L] && P->b[L], STDADK_E_ARG, "mlp_forward: output layer weights NULL");
   if (tail_enabled() && !c.masks && L >= 1 && tail_supported(d, 1)) {
     int l = l0;
-    if (l == 0) {
+    TailFwdArgs a;
+    a.d0.on = 0;
+    if (l == 0 && c.d0) {
+      // layer 0 inside the tail launch: features of a row tile in LDS, W0^T rows as the B operand
+      static const float cals[3] = {1.000000f, 0.223477f, 0.654714f};  // st_interp.py:56-60
+      const stdadk_basis_desc *b = c.basis;
+      TailDense0 &z = a.d0;
+      z.on = 1;
+      z.coords = c.d0_coords; z.t = c.d0_t; z.X = c.d0_X;
+      z.p = b->p; z.Ks = (int)b->Ks; z.Kt = (int)b->Kt; z.basis = b->basis; z.cal = cals[b->basis];
+      z.s_centers = b->s_centers; z.s_bw = c.d0_bw; z.t_centers = b->t_centers; z.t_bw = b->t_bw;
+      z.feats = c.save ? ws + pl.feats : nullptr; z.ldf = pl.ldf;
+      z.W0T = P->W[0];
+      z.L0 = tail_layer(c, 0);
+      if (!c.save) z.L0.xhat = z.L0.rstd = z.L0.act = nullptr;
+      l = 1;
+    } else if (l == 0) {
       rc = generic_layer_forward(c, 0, in, ld_in, K);
       if (rc) return rc;
       l = 1;
     }
-    TailFwdArgs a;
     a.n_layers = L - l;
     for (int i = l; i < L; ++i) {
       STDADK_REQUIRE(P->W[i] && P->b[i] && (!d->layernorm || (P->ln_g[i] && P->ln_b[i])), STDADK_E_ARG,
@@ -1111,6 +1129,17 @@ static int step_forward(Ctx &c, const stdadk_basis_desc *b, bool window, const f
     rc = launch_exp(b->s_bw, b->Ks, ws + c.pl.bw_exp, c.st);
     if (rc) return rc;
     s_bw = ws + c.pl.bw_exp;
+  }
+  // small feature width, (in,out) first weight, fused tail available: features and layer 0 inside the tail
+  // launch (environment STDADK_NO_DENSE0_TAIL=1: the separate kernels, diagnostic)
+  c.d0 = c.w0t && d->in_dim <= TAIL_D0_MAX && d->n_hidden >= 1 && tail_enabled() && !c.masks && tail_supported(d, 1) &&
+         c.pl.ldf == ((d->in_dim + 31) & ~31) && getenv("STDADK_NO_DENSE0_TAIL") == nullptr;
+  if (c.d0) {
+    c.basis = b;
+    c.d0_coords = coords; c.d0_t = t; c.d0_X = X; c.d0_bw = s_bw;
+    rc = run_forward(c, 0, nullptr, 0, d->in_dim, y_pred);
+    c.d0 = false;
+    return rc;
   }
   rc = stdadk_rbf_build_f32(coords, t, X, c.B, b->p, b->s_centers, s_bw, b->Ks, b->basis, b->t_centers,
                             b->t_bw, b->Kt, ws + c.pl.feats, c.pl.ldf, stream);

@@ -26,9 +26,28 @@ struct TailLayer {
   int layer_id;        // index in the model (dropout stream id)
 };
 
+// Materialising path with a small feature width (D <= TAIL_D0_MAX, first weight stored (in,out)): the launch
+// starts from the raw observations -- it evaluates [X | phi | psi] of its rows into LDS (and into the
+// feature buffer the backward reads), runs layer 0 as a GEMM over them and continues with the tail layers;
+// replaces stdadk_rbf_build_f32 + the layer-0 GEMM + its LayerNorm/ReLU/Dropout kernel (3 launches).
+constexpr int TAIL_D0_MAX = 2 * TAIL_MAX_W;
+struct TailDense0 {
+  int on;                           // 0: the launch starts from a_in (activations of the layer before)
+  const float *coords, *t, *X;      // [B][2], [B], [B][p]
+  int p, Ks, Kt, basis;
+  float cal;                        // calibration factor of the basis (st_interp.py:56-60)
+  const float *s_centers, *s_bw;    // [Ks][2], [Ks] (bandwidths, not logs)
+  const float *t_centers, *t_bw;    // [Kt]
+  float *feats;                     // [B][ldf] or NULL (eval mode)
+  int64_t ldf;                      // = D rounded up to 32
+  const float *W0T;                 // [D][h0]
+  TailLayer L0;                     // b, g, be, h = h0, hp = D, xhat, rstd, act, layer_id = 0 (W unused)
+};
+
 struct TailFwdArgs {
   int n_layers;                 // tail hidden layers in this launch (may be 0: head only)
   TailLayer L[TAIL_MAX_LAYERS];
+  TailDense0 d0;
   const float *a_in;            // [B][h_in] input activations of the first tail layer
   int h_in;
   int B;

@@ -11,11 +11,12 @@
 
 namespace stdadk {
 
-template <int MT>
+// D0: the launch starts from the raw observations (TailDense0 in tail.h)
+template <int MT, bool D0>
 __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[TT / 64];
-  tail_fwd_body<MT>(a, smem, red, blockIdx.x);
+  tail_fwd_body<MT, D0>(a, smem, red, blockIdx.x);
 }
 
 template <int MT>
@@ -29,11 +30,11 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
 // what the forward just wrote in L2).  The forward's global stores (xhat, act, rstd, dY) are complete
 // and visible to the whole workgroup after the __syncthreads() (vmcnt(0) + barrier); none of those lines
 // was read by this CU earlier in the launch, so no stale copy can sit in its L1.
-template <int MT>
+template <int MT, bool D0>
 __global__ __launch_bounds__(TT) void tail_fwd_bwd_kernel(TailFwdArgs f, TailBwdArgs b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[TT / 64];
-  tail_fwd_body<MT>(f, smem, red, blockIdx.x);
+  tail_fwd_body<MT, D0>(f, smem, red, blockIdx.x);
   __syncthreads();
   tail_bwd_body<MT>(b, smem, blockIdx.x);
 }
@@ -63,24 +64,38 @@ int tail_rows(int64_t B) {
   return ceil_div(B, 32) >= 256 ? 32 : 16;
 }
 
-template <int MT>
+static int check_d0(const TailFwdArgs &a) {
+  if (!a.d0.on) return 0;
+  const TailDense0 &z = a.d0;
+  const int D = z.p + z.Ks + z.Kt;
+  STDADK_REQUIRE(D >= 1 && D <= TAIL_D0_MAX && z.L0.hp == D && z.ldf == ((D + 31) & ~31) && z.W0T && z.coords && z.t &&
+                     (z.p == 0 || z.X) && z.L0.h <= TAIL_MAX_W && (z.L0.h & 15) == 0,
+                 STDADK_E_ARG, "tail: dense layer 0 needs D <= %d, ldf = D rounded up to 32 and h0 <= %d", TAIL_D0_MAX,
+                 TAIL_MAX_W);
+  return 0;
+}
+
+template <int MT, bool D0>
 static int launch_fwd(const TailFwdArgs &a, hipStream_t st) {
   constexpr int R = 16 * MT;
   static bool attr_done = false;
   if (!attr_done) {   // once per process, never inside a stream capture (the first step runs eagerly)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel<MT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel<MT, D0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds(R));
     if (e != hipSuccess) { set_error("tail_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  STDADK_LAUNCH_NAMED("tail_fwd_kernel", (tail_fwd_kernel<MT>), dim3((unsigned)ceil_div(a.B, R)), dim3(TT), fwd_lds(R), st, a);
+  STDADK_LAUNCH_NAMED(D0 ? "tail_fwd_kernel<dense0>" : "tail_fwd_kernel", (tail_fwd_kernel<MT, D0>),
+                      dim3((unsigned)ceil_div(a.B, R)), dim3(TT), fwd_lds(R), st, a);
   STDADK_CHECK_LAUNCH("tail_forward");
   return 0;
 }
 
 int tail_forward(const TailFwdArgs &a, hipStream_t st) {
   const int r = tail_rows(a.B);
-  return r == 64 ? launch_fwd<4>(a, st) : (r == 32 ? launch_fwd<2>(a, st) : launch_fwd<1>(a, st));
+  if (int rc = check_d0(a)) return rc;
+  if (a.d0.on) return r == 64 ? launch_fwd<4, true>(a, st) : (r == 32 ? launch_fwd<2, true>(a, st) : launch_fwd<1, true>(a, st));
+  return r == 64 ? launch_fwd<4, false>(a, st) : (r == 32 ? launch_fwd<2, false>(a, st) : launch_fwd<1, false>(a, st));
 }
 
 template <int MT>
@@ -98,25 +113,31 @@ static int launch_bwd(const TailBwdArgs &a, hipStream_t st) {
   return 0;
 }
 
-template <int MT>
+template <int MT, bool D0>
 static int launch_fwd_bwd(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st) {
   constexpr int R = 16 * MT;
   const size_t lds = fwd_lds(R) > bwd_lds(R) ? fwd_lds(R) : bwd_lds(R);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_bwd_kernel<MT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_bwd_kernel<MT, D0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("tail_forward_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  STDADK_LAUNCH_NAMED("tail_fwd_bwd_kernel", (tail_fwd_bwd_kernel<MT>), dim3((unsigned)ceil_div(f.B, R)), dim3(TT), lds, st, f, b);
+  STDADK_LAUNCH_NAMED(D0 ? "tail_fwd_bwd_kernel<dense0>" : "tail_fwd_bwd_kernel", (tail_fwd_bwd_kernel<MT, D0>),
+                      dim3((unsigned)ceil_div(f.B, R)), dim3(TT), lds, st, f, b);
   STDADK_CHECK_LAUNCH("tail_forward_backward");
   return 0;
 }
 
 int tail_forward_backward(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st) {
   const int r = tail_rows(f.B);
-  return r == 64 ? launch_fwd_bwd<4>(f, b, st) : (r == 32 ? launch_fwd_bwd<2>(f, b, st) : launch_fwd_bwd<1>(f, b, st));
+  if (int rc = check_d0(f)) return rc;
+  if (f.d0.on)
+    return r == 64 ? launch_fwd_bwd<4, true>(f, b, st)
+                   : (r == 32 ? launch_fwd_bwd<2, true>(f, b, st) : launch_fwd_bwd<1, true>(f, b, st));
+  return r == 64 ? launch_fwd_bwd<4, false>(f, b, st)
+                 : (r == 32 ? launch_fwd_bwd<2, false>(f, b, st) : launch_fwd_bwd<1, false>(f, b, st));
 }
 
 int tail_backward(const TailBwdArgs &a, hipStream_t st) {

@@ -2,6 +2,7 @@
 // fused training-step kernel (fused_step.hip).  `tile` = index of the row tile (R rows) a workgroup carries.
 #pragma once
 #include "tail.h"
+#include "basis.h"
 
 namespace stdadk {
 
@@ -125,6 +126,75 @@ __device__ __forceinline__ void preload_w_kn(BFrag<1> &f, const float *__restric
 // LDS staging, no workgroup barrier in the K loop), two 32-deep chunks in flight.
 
 // ---------------------------------------------------------------------------------------------
+// layer 0 from the raw observations (TailDense0)
+// ---------------------------------------------------------------------------------------------
+// [X | phi | psi] of rows row0.. of the batch into LDS: columns [0, 256) in act0, [256, 512) in act1, zero beyond
+// D; and into the feature buffer (row stride ldf = D rounded up to 32, padding zero) for the backward.
+// Same arithmetic as rbf_build_kernel (phi_eval / psi_eval of basis.h).
+template <int MT>
+__device__ __forceinline__ void d0_fill_features(const TailDense0 &z, float *act0, float *act1, int row0, int B) {
+  constexpr int R = 16 * MT;
+  const int D = z.p + z.Ks + z.Kt;
+  const int Dp = (D + 31) & ~31;
+  for (int idx = threadIdx.x; idx < R * Dp; idx += TT) {
+    const int row = idx / Dp, col = idx - row * Dp;
+    const int grow = min(row0 + row, B - 1);
+    float v = 0.f;
+    if (col < z.p) {
+      v = z.X[(size_t)grow * z.p + col];
+    } else if (col < z.p + z.Ks) {
+      const int k = col - z.p;
+      const float x = z.coords[2 * grow], y = z.coords[2 * grow + 1];
+      const float cx = z.s_centers[2 * k], cy = z.s_centers[2 * k + 1];
+      const float sc = knot_scale(z.s_bw[k], z.cal);
+      v = z.basis == STDADK_BASIS_WENDLAND ? phi_eval<STDADK_BASIS_WENDLAND>(x, y, cx, cy, sc)
+          : (z.basis == STDADK_BASIS_GAUSSIAN ? phi_eval<STDADK_BASIS_GAUSSIAN>(x, y, cx, cy, sc)
+                                              : phi_eval<STDADK_BASIS_TRIANGULAR>(x, y, cx, cy, sc));
+    } else if (col < D) {
+      const int j = col - z.p - z.Ks;
+      v = psi_eval(z.t[grow], z.t_centers[j], z.t_bw[j]);
+    }
+    if (col < TAIL_MAX_W) act0[row * ACT_LD + col] = v;
+    else act1[row * ACT_LD + col - TAIL_MAX_W] = v;
+    if (z.feats && row0 + row < B) z.feats[(size_t)(row0 + row) * z.ldf + col] = v;
+  }
+  // LDS columns [Dp, 256) / [Dp - 256, 256) are never read: the GEMM below stops at Dp
+}
+
+// B fragment of chunk c from W0^T [D][N] with every row index clamped below D (the A columns there are zero)
+__device__ __forceinline__ void d0_load_bfrag(BFrag<1> &f, const float *__restrict__ W0T, int N, int D, int c, int wave,
+                                              int c16, int q) {
+  const int n = 16 * wave + c16;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = 32 * c + 16 * j + 4 * q;
+    const float *b = W0T + n;
+    f.v[j] = make_float4(b[(size_t)min(k, D - 1) * N], b[(size_t)min(k + 1, D - 1) * N],
+                         b[(size_t)min(k + 2, D - 1) * N], b[(size_t)min(k + 3, D - 1) * N]);
+  }
+}
+
+// acc += features (LDS, two 256-column halves) . W0^T, 32-deep chunks, two in flight like gemm16_pre
+template <int MT>
+__device__ __forceinline__ void d0_gemm(f32x4 (*acc)[MAX_NI], const float *act0, const float *act1,
+                                        const float *__restrict__ W0T, int N, int D, int wave, int c16, int q,
+                                        BFrag<1> &f0) {
+  if (wave >= (N >> 4)) return;
+  const int Kp = (D + 15) & ~15;                 // mma_chunk works in 16-deep halves
+  const int nchunk = (D + 31) >> 5;
+  constexpr int HC = TAIL_MAX_W / 32;            // chunks per LDS half
+  BFrag<1> f1;
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 1 < nchunk) d0_load_bfrag(f1, W0T, N, D, c + 1, wave, c16, q);
+    mma_chunk<1, MT>(acc, f0, c < HC ? act0 : act1 - TAIL_MAX_W, Kp, c, c16, q);
+    if (c + 1 < nchunk) {
+      if (c + 2 < nchunk) d0_load_bfrag(f0, W0T, N, D, c + 2, wave, c16, q);
+      mma_chunk<1, MT>(acc, f1, c + 1 < HC ? act0 : act1 - TAIL_MAX_W, Kp, c + 1, c16, q);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 #ifdef STDADK_DIAG   // diagnostic build only: in-kernel wall-clock stamps of the phases
@@ -132,7 +202,7 @@ __device__ __forceinline__ void preload_w_kn(BFrag<1> &f, const float *__restric
 #else
 #define STAMP(i) do { } while (0)
 #endif
-template <int MT>
+template <int MT, bool D0 = false>
 __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem, float *red, const int tile) {
   constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
   float *act0 = smem, *act1 = smem + R * ACT_LD;
@@ -142,8 +212,13 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
   const int row0 = tile * R;
   STAMP(0);
   BFrag<1> wpre;
-  if (a.n_layers > 0) preload_w(wpre, a.L[0].W, a.L[0].h, a.L[0].hp, wave, c16, q);
-  {
+  if constexpr (D0) {
+    if (wave < (a.d0.L0.h >> 4)) d0_load_bfrag(wpre, a.d0.W0T, a.d0.L0.h, a.d0.L0.hp, 0, wave, c16, q);
+    d0_fill_features<MT>(a.d0, act0, act1, row0, a.B);
+  } else {
+    if (a.n_layers > 0) preload_w(wpre, a.L[0].W, a.L[0].h, a.L[0].hp, wave, c16, q);
+  }
+  if constexpr (!D0) {
     // input tile: unconditional loads from clamped rows (rows >= B duplicate the last row; nothing
     // computed for them is ever stored), 4 per thread in flight
     const int v4 = a.h_in >> 2;            // <= 64 float4 per row => R*v4 <= 64*R
@@ -170,14 +245,14 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
   float *cur = act0, *nxt = act1;
   STAMP(1);
   // output-layer weights of q = 0 (the MSE head has Q = 1): requested now, used at the very end
-  const int hl_head = a.n_layers ? a.L[a.n_layers - 1].h : a.h_in;
+  const int hl_head = a.n_layers ? a.L[a.n_layers - 1].h : (D0 ? a.d0.L0.h : a.h_in);
   float wo0[4];
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) wo0[cc] = a.Wo[min(lane + 64 * cc, hl_head - 1)];
   const float bo0 = a.bo[0];
 
-  for (int li = 0; li < a.n_layers; ++li) {
-    const TailLayer &L = a.L[li];
+  for (int li = D0 ? -1 : 0; li < a.n_layers; ++li) {
+    const TailLayer &L = li < 0 ? a.d0.L0 : a.L[li];     // li = -1: layer 0 from the features in LDS
     const int h = L.h, hp = L.hp;
     const int NT = h >> 4;
     // LayerNorm parameters of this layer: requested before the GEMM, consumed after it (one L2 round
@@ -194,9 +269,14 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre);
+    if (D0 && li < 0) {
+      d0_gemm<MT>(acc, act0, act1, a.d0.W0T, h, hp, wave, c16, q, wpre);
+      if (hp > TAIL_MAX_W) lds_barrier();        // z goes into act1, which held the second half of the features
+    } else {
+      gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre);
+    }
     if (li + 1 < a.n_layers) preload_w(wpre, a.L[li + 1].W, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q);
-    STAMP(2 + 4 * li);
+    STAMP(2 + 4 * (li < 0 ? 0 : li));
     // z = acc + bias into the other activation buffer
 #pragma unroll
     for (int i = 0; i < MAX_NI; ++i) {
@@ -211,7 +291,7 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
       }
     }
     lds_barrier();
-    STAMP(3 + 4 * li);
+    STAMP(3 + 4 * (li < 0 ? 0 : li));
     // LayerNorm -> ReLU -> Dropout, wave w owns rows RPW*w .. RPW*w+RPW-1
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
@@ -256,14 +336,14 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
         }
       }
     }
-    STAMP(4 + 4 * li);
+    STAMP(4 + 4 * (li < 0 ? 0 : li));
     lds_barrier();
-    STAMP(5 + 4 * li);
+    STAMP(5 + 4 * (li < 0 ? 0 : li));
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
 
   // output layer (+ loss): y[row][qq] = a_last[row,:] . Wo[qq,:] + bo[qq]
-  const int hl = a.n_layers ? a.L[a.n_layers - 1].h : a.h_in;
+  const int hl = hl_head;
   float lsum = 0.f;
   const bool plain_mse = a.loss.kind == STDADK_LOSS_MSE && a.loss.y_cols == a.Q;
 #pragma unroll

@@ -1663,3 +1663,38 @@ def test_knot_groups_are_bit_identical(name, monkeypatch):
         for ga, gb in zip(res[nk][0], res["1"][0]):
             assert torch.equal(ga, gb), nk
         assert torch.equal(res[nk][1], res["1"][1]), nk
+
+
+@pytest.mark.parametrize("name", ["tiny9_ln_p3", "default227", "default227_gauss", "default227_noln"])
+def test_dense_layer0_inside_tail_launch(name, monkeypatch):
+    """Materialising path, D <= 512: features + layer 0 evaluated inside the tail launch (one kernel from the raw
+    observations to the activation gradients) against the separate kernels (stdadk_rbf_build_f32, the layer-0
+    GEMM, its LayerNorm/ReLU/Dropout kernel): same feature arithmetic, another GEMM summation order."""
+    from stnf.engine import TrainStep
+    cfg = cases.MODEL_CASES[name]
+    d = dev()
+    rs = np.random.RandomState(8)
+    n = 777                      # ragged against the 16-row tiles
+    c2 = torch.from_numpy(rs.uniform(-0.05, 1.05, (n, 2)).astype(np.float32)).to(d)
+    t2 = torch.from_numpy(rs.uniform(0, 1, (n, 1)).astype(np.float32)).to(d)
+    X2 = torch.from_numpy(rs.standard_normal((n, cfg["p"])).astype(np.float32)).to(d) if cfg["p"] else None
+    y2 = torch.from_numpy(rs.standard_normal((n, 1)).astype(np.float32)).to(d)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("STDADK_NO_DENSE0_TAIL", "1")
+        m = build_model(cfg, dropout=0.1)
+        m.train()
+        eng = TrainStep(m, lr=1e-3, ema_decay=0.99, max_batch=n, force_dense=True)
+        assert not eng.uses_window
+        for _ in range(3):
+            eng.step(X2, c2, t2, y2)
+        loss = eng.mean_loss()
+        m.eval()
+        with torch.no_grad():
+            ye = m(X2, c2, t2).clone()        # engine-owned (in,out) storage: the eval forward takes the same path
+        res.append((loss, eng.flat.clone(), ye))
+    monkeypatch.delenv("STDADK_NO_DENSE0_TAIL", raising=False)
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * max(1.0, abs(res[1][0]))
+    assert rel_l2(res[0][1].cpu().numpy(), res[1][1].cpu().numpy()) <= 2e-6
+    assert rel_l2(res[0][2].cpu().numpy(), res[1][2].cpu().numpy()) <= 2e-6
