@@ -22,6 +22,9 @@ _SCOPE_MSG = ("is not built: it needs the k_means_constrained package, which thi
               "(the reference imports it lazily in the same place, st_interp.py:362)")
 
 
+_DENSE0_MAX_D = 512        # TAIL_D0_MAX of csrc/tail.h
+
+
 def _round_up(a, b):
     return (a + b - 1) // b * b
 
@@ -436,7 +439,10 @@ class STInterpMLP(nn.Module):
         if not w0.is_contiguous() and w0.t().is_contiguous():
             tensors[0] = w0.t()                                  # engine-owned (in,out) storage
             flags |= N.FLAG_W0_T
-        elif not force_dense and N.step_uses_window(st.basis, st.desc, flags | N.FLAG_W0_T):
+        elif (not force_dense and N.step_uses_window(st.basis, st.desc, flags | N.FLAG_W0_T)) \
+                or self.input_dim <= _DENSE0_MAX_D:
+            # window path, or a feature width small enough for the library to run layer 0 inside the tail
+            # launch of the materialising path: both want the first weight as (in,out)
             st.keep = w0.t().contiguous()
             tensors[0] = st.keep
             flags |= N.FLAG_W0_T
