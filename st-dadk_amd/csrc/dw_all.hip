@@ -16,12 +16,16 @@ template <int CPL, int BASIS, bool KNOTS, int NK>
 __global__ __launch_bounds__(GT) void dw_all_kernel(GemmGroup grp, int n_gemm_blocks, L1BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[TileGeom<64, true>::SIZE * 2];
   // GEMM tiles take the low block ids (dispatched first): measured 33.5 us vs 42.5 us the other way round
-  if ((int)blockIdx.x < n_gemm_blocks) gemm_tn_grouped_block(grp, (int)blockIdx.x, lds);
-  else if constexpr (NK > 1) l1_window_bwd_multi_body<CPL, BASIS, NK>(a, (int)blockIdx.x - n_gemm_blocks);
-  else l1_window_bwd_body<CPL, BASIS, KNOTS>(a, (int)blockIdx.x - n_gemm_blocks);
+  if ((int)blockIdx.x < n_gemm_blocks) { gemm_tn_grouped_block(grp, (int)blockIdx.x, lds); return; }
+  // XCD-striped knot groups start at a multiple of 8, so that (group block & 7) is the XCD of the workgroup
+  const int first = a.xcd_slots > 0 ? (n_gemm_blocks + 7) & ~7 : n_gemm_blocks;
+  if ((int)blockIdx.x < first) return;
+  if constexpr (NK > 1) l1_window_bwd_multi_body<CPL, BASIS, NK>(a, (int)blockIdx.x - first);
+  else l1_window_bwd_body<CPL, BASIS, KNOTS>(a, (int)blockIdx.x - first);
 }
 
-int launch_dw_all(GemmGroup &grp, const L1BwdArgs &a, int basis, hipStream_t st) {
+int launch_dw_all(GemmGroup &grp, const L1BwdArgs &a_in, int basis, hipStream_t st) {
+  L1BwdArgs a = a_in;
   STDADK_REQUIRE(a.G <= 256, STDADK_E_ARG, "dw_all: G too large");
   STDADK_REQUIRE((int64_t)a.B * a.H < (1ll << 32), STDADK_E_ARG, "dw_all: B*H exceeds 32-bit offsets");
   STDADK_REQUIRE(!a.kpart || a.W0T, STDADK_E_ARG, "dw_all: knot sums need W0^T");
@@ -29,7 +33,9 @@ int launch_dw_all(GemmGroup &grp, const L1BwdArgs &a, int basis, hipStream_t st)
   int rc = gemm_tn_grouped_prepare(grp, &ng);
   if (rc) return rc;
   const int nk = knots_per_wave(a);
-  const unsigned grid = (unsigned)ng + (unsigned)ceil_div(knot_group_count(a.g, nk), BW_T / 64);
+  a.xcd_slots = nk == 2 ? knot_xcd_slots(a.g) : 0;
+  const unsigned grid = a.xcd_slots > 0 ? (unsigned)((ng + 7) & ~7) + 8u * (unsigned)a.xcd_slots
+                                        : (unsigned)ng + (unsigned)ceil_div(knot_group_count(a.g, nk), BW_T / 64);
 #define GO(CPL_, BS_)                                                                                      \
   do {                                                                                                     \
     if (a.kpart) STDADK_LAUNCH_NAMED("dw_all_kernel<knots>", (dw_all_kernel<CPL_, BS_, true, 1>),          \

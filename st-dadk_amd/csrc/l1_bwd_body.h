@@ -202,17 +202,40 @@ __device__ __forceinline__ void l1_window_bwd_multi_body(const L1BwdArgs &a, con
   __shared__ float lphi[BW_T / 64][NK][BW_LIST + 8];
   __shared__ int lidx[BW_T / 64][BW_LIST + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int q = block * (BW_T / 64) + wave;                 // group index, level by level
-  int l = 0;
-  for (; l < a.g.n_levels; ++l) {
+  int l = 0, ix, iy;
+  if (NX == 1 && a.xcd_slots > 0) {
+    // XCD-aware order: workgroup `block` runs on XCD block & 7 (round-robin dispatch; the launch pads the
+    // blocks before the knot groups to a multiple of 8).  XCD x owns the grid rows [x side/8, (x+1) side/8) of
+    // every level: its knots see the observations of one stripe of the domain (+ halo), a contiguous eighth of
+    // the cell-sorted dZ rows, so each XCD's L2 fetches about 1/5 of dZ_0 instead of all of it.
+    const int x = block & 7;
+    int q = (block >> 3) * (BW_T / 64) + wave;        // group index inside XCD x's list, level by level
+    int r0 = 0;
+    for (; l < a.g.n_levels; ++l) {
+      const int side = a.g.side[l], hp = (side + 1) >> 1;
+      r0 = (x * side) >> 3;
+      const int np = ((((x + 1) * side) >> 3) - r0) * hp;
+      if (q < np) break;
+      q -= np;
+    }
+    if (l >= a.g.n_levels) return;
     const int hp = (a.g.side[l] + 1) >> 1;
-    const int np = (NX == 2 ? hp : a.g.side[l]) * hp;
-    if (q < np) break;
-    q -= np;
+    const int gx = q / hp;
+    ix = r0 + gx; iy = 2 * (q - gx * hp);
+  } else {
+    int q = block * (BW_T / 64) + wave;               // group index, level by level
+    for (; l < a.g.n_levels; ++l) {
+      const int hp = (a.g.side[l] + 1) >> 1;
+      const int np = (NX == 2 ? hp : a.g.side[l]) * hp;
+      if (q < np) break;
+      q -= np;
+    }
+    if (l >= a.g.n_levels) return;
+    const int hp = (a.g.side[l] + 1) >> 1;
+    const int gx = q / hp;
+    ix = NX * gx; iy = 2 * (q - gx * hp);
   }
-  if (l >= a.g.n_levels) return;
-  const int side = a.g.side[l], hp = (side + 1) >> 1;
-  const int gx = q / hp, ix = NX * gx, iy = 2 * (q - gx * hp);
+  const int side = a.g.side[l];
   int kk[NK];
   bool has[NK];
   float kx[NK], ky[NK], ksc[NK];

@@ -68,6 +68,7 @@ bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt);
 struct L1BwdArgs;
 int knot_group_count(const GridView &g, int nk);  // groups of the per-knot gather of dW0^T, nk knots per wave
 int knots_per_wave(const L1BwdArgs &a);
+int knot_xcd_slots(const GridView &g);            // workgroups per XCD of the XCD-striped pair order, 0 = off
 
 struct L1BwdArgs {
   GridView g;
@@ -76,6 +77,8 @@ struct L1BwdArgs {
   int G, B, H;
   const float *dZ;      // [B][H] sorted order
   float *dW0T;          // [D][H]
+  int xcd_slots = 0;    // > 0: two-knots-per-wave groups in XCD-striped order, this many workgroups per XCD
+                        // (set by the launchers, see knot_xcd_slots)
   // learnable knots: W0^T (rows p + k) and the raw knot sums [3][Ks] (d cx, d cy, d log_bw) this kernel
   // also produces; NULL = fixed knots
   const float *W0T;

@@ -466,6 +466,23 @@ int knot_group_count(const GridView &g, int nk) {
   return n;
 }
 
+// XCD-striped order of the pair groups: workgroups per XCD = the longest of the eight lists (equal when every
+// side is a multiple of 8); environment STDADK_KNOT_XCD=0 switches the striping off (diagnostic)
+int knot_xcd_slots(const GridView &g) {
+  const char *e = getenv("STDADK_KNOT_XCD");
+  if (e && e[0] == '0') return 0;
+  int most = 0;
+  for (int x = 0; x < 8; ++x) {
+    int n = 0;
+    for (int l = 0; l < g.n_levels; ++l) {
+      const int side = g.side[l];
+      n += ((((x + 1) * side) >> 3) - ((x * side) >> 3)) * ((side + 1) / 2);
+    }
+    most = n > most ? n : most;
+  }
+  return (int)ceil_div(most, BW_T / 64);
+}
+
 // knots per wave of the per-knot gather: learnable knots 1; fixed grid knots 2 (environment
 // STDADK_KNOTS_PER_WAVE = 1 | 2 overrides, diagnostic).  Measured on MI355X, C2 model: 2 per wave is
 // -2.5 us on the merged weight-gradient launch at B = 4096 and -14 % on it at B = 65 536; blocks of 2 x 2
@@ -484,7 +501,9 @@ int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st) {
   STDADK_REQUIRE(a.G <= 256, STDADK_E_ARG, "l1_window_backward: G too large");
   STDADK_REQUIRE((int64_t)a.B * a.H < (1ll << 32), STDADK_E_ARG, "l1_window_backward: B*H exceeds 32-bit offsets");
   const int nk = knots_per_wave(a);
-  const unsigned grid = (unsigned)ceil_div(knot_group_count(a.g, nk), BW_T / 64);
+  a.xcd_slots = nk == 2 ? knot_xcd_slots(a.g) : 0;
+  const unsigned grid = a.xcd_slots > 0 ? 8u * (unsigned)a.xcd_slots
+                                        : (unsigned)ceil_div(knot_group_count(a.g, nk), BW_T / 64);
   STDADK_REQUIRE(!a.kpart || a.W0T, STDADK_E_ARG, "l1_window_backward: knot sums need W0^T");
 #define GO(CPL_, BS_)                                                                                        \
   do {                                                                                                       \

@@ -1,5 +1,6 @@
 """Train step of the C2 model with one or two knots per wave in the per-knot gather of dW0^T
-(STDADK_KNOTS_PER_WAVE=1|2), several batch sizes.  usage (MI355X box): python tools/bench_knot_pairs.py"""
+(STDADK_KNOTS_PER_WAVE=1|2), pair groups in table order or XCD-striped
+(STDADK_KNOT_XCD=0|1), several batch sizes.  usage (MI355X box): python tools/bench_knot_pairs.py"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,9 +17,10 @@ t = torch.randint(0, 100, (N_OBS, 1), device=d).float() / 99
 y = torch.randn(N_OBS, 1, device=d)
 mk = dict(p=0, k_spatial_centers=[1024, 4096, 5184], k_temporal_centers=[10, 15, 45], hidden_dims=[256, 256, 128],
           dropout=0.1, layernorm=True)
-for pairs in ("1", "2"):
+for pairs, xcd in (("1", "1"), ("2", "0"), ("2", "1")):
     os.environ["STDADK_KNOTS_PER_WAVE"] = pairs
-    line = [f"knots_per_wave={pairs}"]
+    os.environ["STDADK_KNOT_XCD"] = xcd
+    line = [f"knots_per_wave={pairs} xcd_striped={xcd}"]
     for B in (4096, 8192, 16384, 65536):
         m = STInterpMLP(**mk).to(d)
         m.train()
