@@ -634,7 +634,7 @@ def test_engine_two_streams_equals_one():
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])   # the loss is summed with float atomics
     # Same kernels and the same order of every gradient sum; only the clip norm differs in its last bits
     # (one stream: partials out of the reductions launch, 512 of them; two streams: stdadk_sumsq_f32, 256).
-    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=3e-7)
 
 
 @pytest.mark.parametrize("name,dense,clip", [("c2_b257", False, 1.0), ("c2_b257", False, 0.0),
@@ -670,8 +670,8 @@ def test_one_call_step_equals_split_calls(name, dense, clip):
     if clip == 0.0:
         assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     else:   # the squared norm is summed in a different order
-        torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=1e-7)
-        torch.testing.assert_close(res[0][2], res[1][2], rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=3e-7)
+        torch.testing.assert_close(res[0][2], res[1][2], rtol=2e-6, atol=3e-7)
 
 
 def test_reference_style_loop_matches_engine():
