@@ -399,6 +399,21 @@ def main():
             dt = (time.perf_counter() - t1) / 20
             out["variants"]["inference_forward_only"] = {"obs_per_s": n_inf / dt, "ms_per_call": dt * 1e3,
                                                          "rows_per_call": n_inf, "path": "window"}
+            # the same forward on a site x time grid (what the reference's dense-grid callers loop over: the same
+            # sites at every time): the per-site half of layer 0 is evaluated once per site
+            S_g, T_g = min(n_obs, 100000), 20
+            tv = torch.arange(T_g, device=dev, dtype=torch.float32) / (T_g - 1)
+            cg = coords[:S_g].contiguous()
+            for _ in range(2):
+                pr.predict_grid(cg, tv)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                pr.predict_grid(cg, tv)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 5
+            out["variants"]["inference_site_x_time_grid"] = {"obs_per_s": S_g * T_g / dt, "ms_per_call": dt * 1e3,
+                                                             "sites": S_g, "times": T_g, "path": "window"}
             model.train()
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, B, args.dropout)

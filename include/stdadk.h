@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STDADK_ABI_VERSION 4
+#define STDADK_ABI_VERSION 5
 #define STDADK_MAX_HIDDEN 8
 #define STDADK_MAX_LEVELS 8
 #define STDADK_SUMSQ_PARTS 256 /* partial sums written by stdadk_sumsq_f32 */
@@ -396,6 +396,25 @@ int stdadk_train_step_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc 
                           const stdadk_sparsity_desc *sparsity, float *loss_sum, void *workspace,
                           size_t workspace_bytes, uint64_t drop_seed, int32_t flags,
                           const stdadk_optim_desc *opt, stdadk_stream_t stream);
+
+/* A10 on a site x time prediction grid (the dense inference callers loop over time slices with the SAME S
+ * sites in each, scripts/train_st_interp.py:1091-1107,1232-1248,1378-1409).  Layer 0's pre-activation of row
+ * (ti, s) is  sum_k phi_k(s) W0^T[p+k,:]  +  sum_j psi_j(t_ti) W0^T[p+Ks+j,:]  +  b0 : a per-site row plus a per-time
+ * row, so the basis evaluation and the W0^T gather are done once per site instead of once per (site, time):
+ *   stdadk_spatial_partial_f32   sp[S][h0]  (window path, fixed grid knots, p = 0; workspace as for a forward of S rows)
+ *   stdadk_temporal_partial_f32  tp[T][h0]
+ *   stdadk_forward_parts_f32     y_pred[T*S][Q], rows time-major: z0 = sp[row % S] + tp[row / S] + b0, then
+ *                                LayerNorm/ReLU of layer 0, the remaining layers and the output layer (eval mode)
+ * Same sums as stdadk_forward_f32 in another order of addition (agreement to fp32 rounding, tested).
+ * All three need the first weight stored (in,out) (STDADK_FLAG_W0_T). */
+int stdadk_spatial_partial_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                               const stdadk_mlp_tensors *params, const float *coords, int64_t S, float *out,
+                               void *workspace, size_t workspace_bytes, int32_t flags, stdadk_stream_t stream);
+int stdadk_temporal_partial_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                                const stdadk_mlp_tensors *params, const float *t_values, int64_t T, float *out,
+                                int32_t flags, stdadk_stream_t stream);
+int stdadk_forward_parts_f32(const stdadk_mlp_desc *mlp, const stdadk_mlp_tensors *params, const float *sp,
+                             int64_t S, const float *tp, int64_t T, float *y_pred, stdadk_stream_t stream);
 
 /* A0, window path: the batch-preparation half of the step on its own — gathers rows idx[b] (NULL = rows
  * 0..B-1) of coords_all / t_all / X_all / y_all [N, y_cols] and bins them into `workspace`, exactly as

@@ -85,7 +85,7 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
     const float x = first ? xf : a.xs[row], y = first ? yf : a.ys[row], t = first ? tf : a.ts[row];
     float acc[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) acc[c] = bias[c];
+    for (int c = 0; c < CPL; ++c) acc[c] = a.raw ? 0.f : bias[c];
 
     // gather-FMA of the first `cnt` list entries (cnt a multiple of 8): 8 rows of W0^T in flight
     auto consume = [&](int cnt) {
@@ -203,6 +203,14 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
       __builtin_amdgcn_wave_barrier();
     }
 
+    if (a.raw) {                           // wave-uniform: the spatial part alone
+      typename VecT<CPL>::T o;
+      float *fo = reinterpret_cast<float *>(&o);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) fo[c] = acc[c];
+      *reinterpret_cast<typename VecT<CPL>::T *>(a.act + (size_t)row * H + CPL * lane) = o;
+      continue;
+    }
     // ---- temporal basis: rows from LDS
     for (int j = lane; j < Kt; j += 64) {
       float v = psi_eval(t, a.g.t_centers[j], a.g.t_bw[j]);
@@ -301,7 +309,7 @@ __device__ __forceinline__ void l1_window_fwd_multi_body(const L1FwdArgs &a, flo
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) acc[r][c] = bf[c];
+        for (int c = 0; c < CPL; ++c) acc[r][c] = a.raw ? 0.f : bf[c];
     }
 
     // gather-FMA of the first `cnt` list entries (cnt a multiple of 8): NF rows of W0^T in flight, R uses of each
@@ -423,6 +431,19 @@ __device__ __forceinline__ void l1_window_fwd_multi_body(const L1FwdArgs &a, flo
       }
     }
 
+    if (a.raw) {                           // wave-uniform: the spatial part alone
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r < nv) {
+          typename VecT<CPL>::T o;
+          float *fo = reinterpret_cast<float *>(&o);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) fo[c] = acc[r][c];
+          *reinterpret_cast<typename VecT<CPL>::T *>(a.act + (size_t)(row + r) * H + CPL * lane) = o;
+        }
+      }
+      continue;
+    }
     // ---- temporal basis: each LDS row feeds the R accumulators
 #pragma unroll
     for (int r = 0; r < R; ++r) {

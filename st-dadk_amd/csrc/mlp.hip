@@ -13,6 +13,7 @@
 #include "window.h"
 #include "tail.h"
 #include "knots.h"
+#include "basis.h"
 
 #include <stdlib.h>
 
@@ -1231,6 +1232,113 @@ extern "C" int stdadk_forward_f32(const stdadk_basis_desc *b, const stdadk_mlp_d
   c.dp = training ? d->dropout_p : 0.f; c.seed = drop_seed; c.step_dev = step_dev;
   c.save = training != 0;
   return step_forward(c, b, window, coords, t, X, nullptr, y_pred, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Site x time prediction grids (A10): layer 0's pre-activation splits into a per-site and a per-time row
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void temporal_partial_kernel(const float *__restrict__ tv, int T, int Kt,
+                                                               const float *__restrict__ tc, const float *__restrict__ tbw,
+                                                               const float *__restrict__ Wt, int H, float *__restrict__ out) {
+  // out[ti][c] = sum_j psi_j(t_ti) Wt[j][c]; one workgroup per time value
+  const int ti = blockIdx.x;
+  const float t = tv[ti];
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < Kt; ++j) acc = fmaf(psi_eval(t, tc[j], tbw[j]), Wt[(size_t)j * H + c], acc);
+    out[(size_t)ti * H + c] = acc;
+  }
+}
+
+extern "C" int stdadk_spatial_partial_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                          const stdadk_mlp_tensors *P, const float *coords, int64_t S, float *out,
+                                          void *workspace, size_t workspace_bytes, int32_t flags,
+                                          stdadk_stream_t stream) {
+  if (S == 0) return 0;
+  Ctx c;
+  bool window;
+  int rc = step_common(c, b, d, S, workspace, workspace_bytes, flags, &window);
+  if (rc) return rc;
+  STDADK_REQUIRE(window && !(flags & STDADK_FLAG_LOG_BW), STDADK_E_ARG,
+                 "spatial_partial: needs the window path with fixed grid knots (compact-support basis, W0 stored (in,out))");
+  STDADK_REQUIRE(b->p == 0, STDADK_E_ARG, "spatial_partial: covariates are per (site, time) row; p must be 0");
+  STDADK_REQUIRE(P && P->W[0] && P->b[0] && coords && out, STDADK_E_ARG, "spatial_partial: NULL pointer");
+  c.P = P; c.st = (hipStream_t)stream;
+  const Plan &pl = c.pl;
+  BinBuffers bb = plan_bins(c.ws, pl);
+  // the sites' x coordinates stand in for the (unused) time column of the binning
+  rc = bin_obs(coords, coords, nullptr, 0, nullptr, 0, (int)S, pl.G, bb, c.st);
+  if (rc) return rc;
+  L1FwdArgs a;
+  a.g = make_grid(b);
+  a.halo = nullptr;
+  a.xs = bb.xs; a.ys = bb.ys; a.ts = bb.ts; a.Xs = nullptr;
+  a.B = (int)S; a.H = d->hidden[0];
+  a.W0T = P->W[0]; a.b0 = P->b[0]; a.gamma = a.beta = nullptr; a.eps = d->ln_eps;
+  a.xhat = a.rstd = a.psi = nullptr; a.ld_psi = pl.ld_psi;
+  a.act = c.ws + pl.act[0];
+  a.drop_p = 0.f; a.seed = 0; a.step_dev = nullptr;
+  a.rows_per_wg = 0; a.n_wg = 0;
+  a.raw = 1;
+  rc = l1_window_forward(a, b->basis, false, c.st);
+  if (rc) return rc;
+  return unpermute_rows(c.ws + pl.act[0], (const int *)(c.ws + pl.perm), (int)S, d->hidden[0], out, c.st);
+}
+
+extern "C" int stdadk_temporal_partial_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                           const stdadk_mlp_tensors *P, const float *t_values, int64_t T,
+                                           float *out, int32_t flags, stdadk_stream_t stream) {
+  if (T == 0) return 0;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  STDADK_REQUIRE(b && P && P->W[0] && t_values && out && T < (1ll << 31), STDADK_E_ARG, "temporal_partial: bad argument");
+  STDADK_REQUIRE((flags & STDADK_FLAG_W0_T) && d->n_hidden >= 1, STDADK_E_ARG,
+                 "temporal_partial: needs the first weight stored (in,out)");
+  const int H = d->hidden[0];
+  STDADK_LAUNCH(temporal_partial_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, t_values, (int)T,
+                (int)b->Kt, b->t_centers, b->t_bw, P->W[0] + (size_t)(b->p + b->Ks) * H, H, out);
+  STDADK_CHECK_LAUNCH("temporal_partial");
+  return 0;
+}
+
+extern "C" int stdadk_forward_parts_f32(const stdadk_mlp_desc *d, const stdadk_mlp_tensors *P, const float *sp,
+                                        int64_t S, const float *tp, int64_t T, float *y_pred,
+                                        stdadk_stream_t stream) {
+  if (S == 0 || T == 0) return 0;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  const int L = d->n_hidden, Q = d->out_dim;
+  STDADK_REQUIRE(P && sp && tp && y_pred && S * T < (1ll << 31), STDADK_E_ARG, "forward_parts: bad argument");
+  STDADK_REQUIRE(L >= 1 && tail_supported(d, 1) && P->W[L] && P->b[L], STDADK_E_ARG,
+                 "forward_parts: hidden widths must be multiples of 16 up to %d, out_dim <= %d", TAIL_MAX_W, TAIL_MAXQ);
+  auto layer = [&](int l) {
+    TailLayer tl;
+    tl.W = P->W[l]; tl.b = P->b[l];
+    tl.g = d->layernorm ? P->ln_g[l] : nullptr; tl.be = d->layernorm ? P->ln_b[l] : nullptr;
+    tl.h = d->hidden[l]; tl.hp = l > 0 ? d->hidden[l - 1] : d->in_dim;
+    tl.xhat = tl.rstd = tl.act = nullptr;
+    tl.layer_id = l;
+    return tl;
+  };
+  TailFwdArgs a;
+  a.n_layers = L - 1;
+  for (int l = 1; l < L; ++l) {
+    STDADK_REQUIRE(P->W[l] && P->b[l] && (!d->layernorm || (P->ln_g[l] && P->ln_b[l])), STDADK_E_ARG,
+                   "forward_parts: layer %d parameters NULL", l);
+    a.L[l - 1] = layer(l);
+  }
+  STDADK_REQUIRE(P->b[0] && (!d->layernorm || (P->ln_g[0] && P->ln_b[0])), STDADK_E_ARG, "forward_parts: layer 0 parameters NULL");
+  a.d0.on = 2; a.d0.sp = sp; a.d0.tp = tp; a.d0.S = (int)S;
+  a.d0.L0 = layer(0);
+  a.a_in = nullptr; a.h_in = d->hidden[0];
+  a.B = (int)(S * T);
+  a.Wo = P->W[L]; a.bo = P->b[L]; a.Q = Q;
+  a.y_pred = y_pred;
+  a.y = nullptr; a.grad_scale = 0.f; a.dY = nullptr; a.loss_sum = nullptr;
+  a.loss = LossDev{STDADK_LOSS_MSE, Q, {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f}, 0.f, 1};
+  a.layernorm = d->layernorm; a.eps = d->ln_eps; a.drop_p = 0.f; a.seed = 0; a.step_dev = nullptr;
+  a.stamps = nullptr;
+  return tail_forward(a, (hipStream_t)stream);
 }
 
 extern "C" int stdadk_backward_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,

@@ -33,6 +33,11 @@ struct TailLayer {
 constexpr int TAIL_D0_MAX = 2 * TAIL_MAX_W;
 struct TailDense0 {
   int on;                           // 0: the launch starts from a_in (activations of the layer before)
+                                    // 1: from the raw observations (fields below)
+                                    // 2: from the two halves of layer 0's pre-activation on a site x time grid:
+                                    //    z0[row] = sp[row % S] + tp[row / S] + b0 (rows time-major), L0 as for 1
+  const float *sp, *tp;             // on = 2: [S][h0] spatial parts, [T][h0] temporal parts
+  int S;
   const float *coords, *t, *X;      // [B][2], [B], [B][p]
   int p, Ks, Kt, basis;
   float cal;                        // calibration factor of the basis (st_interp.py:56-60)

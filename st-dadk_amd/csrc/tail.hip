@@ -67,6 +67,12 @@ int tail_rows(int64_t B) {
 static int check_d0(const TailFwdArgs &a) {
   if (!a.d0.on) return 0;
   const TailDense0 &z = a.d0;
+  if (z.on == 2) {
+    STDADK_REQUIRE(z.sp && z.tp && z.S > 0 && z.L0.b && z.L0.h <= TAIL_MAX_W && (z.L0.h & 15) == 0 && aligned16(z.sp) &&
+                       aligned16(z.tp) && aligned16(z.L0.b),
+                   STDADK_E_ARG, "tail: site x time parts need sp, tp (16-byte aligned), S > 0 and h0 <= %d", TAIL_MAX_W);
+    return 0;
+  }
   const int D = z.p + z.Ks + z.Kt;
   STDADK_REQUIRE(D >= 1 && D <= TAIL_D0_MAX && z.L0.hp == D && z.ldf == ((D + 31) & ~31) && z.W0T && z.coords && z.t &&
                      (z.p == 0 || z.X) && z.L0.h <= TAIL_MAX_W && (z.L0.h & 15) == 0,

@@ -213,8 +213,10 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
   STAMP(0);
   BFrag<1> wpre;
   if constexpr (D0) {
-    if (wave < (a.d0.L0.h >> 4)) d0_load_bfrag(wpre, a.d0.W0T, a.d0.L0.h, a.d0.L0.hp, 0, wave, c16, q);
-    d0_fill_features<MT>(a.d0, act0, act1, row0, a.B);
+    if (a.d0.on == 1) {
+      if (wave < (a.d0.L0.h >> 4)) d0_load_bfrag(wpre, a.d0.W0T, a.d0.L0.h, a.d0.L0.hp, 0, wave, c16, q);
+      d0_fill_features<MT>(a.d0, act0, act1, row0, a.B);
+    }
   } else {
     if (a.n_layers > 0) preload_w(wpre, a.L[0].W, a.L[0].h, a.L[0].hp, wave, c16, q);
   }
@@ -269,7 +271,21 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (D0 && li < 0) {
+    const bool parts = D0 && li < 0 && a.d0.on == 2;    // scalar
+    if (parts) {
+      // site x time grid: the pre-activation of layer 0 is the sum of a per-site and a per-time row
+      const int h4 = h >> 2;
+      for (int idx = tid; idx < R * h4; idx += TT) {
+        const int row = idx / h4, c4 = idx - row * h4;
+        const int grow = min(row0 + row, a.B - 1);
+        const int ti = grow / a.d0.S, si = grow - ti * a.d0.S;
+        const float4 u = *reinterpret_cast<const float4 *>(a.d0.sp + (size_t)si * h + 4 * c4);
+        const float4 w = *reinterpret_cast<const float4 *>(a.d0.tp + (size_t)ti * h + 4 * c4);
+        const float4 bb = *reinterpret_cast<const float4 *>(L.b + 4 * c4);
+        *reinterpret_cast<float4 *>(nxt + row * ACT_LD + 4 * c4) =
+            make_float4((u.x + w.x) + bb.x, (u.y + w.y) + bb.y, (u.z + w.z) + bb.z, (u.w + w.w) + bb.w);
+      }
+    } else if (D0 && li < 0) {
       d0_gemm<MT>(acc, act0, act1, a.d0.W0T, h, hp, wave, c16, q, wpre);
       if (hp > TAIL_MAX_W) lds_barrier();        // z goes into act1, which held the second half of the features
     } else {
@@ -281,7 +297,7 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
 #pragma unroll
     for (int i = 0; i < MAX_NI; ++i) {
       const int t = wave + NW * i;
-      if (t < NT) {
+      if (t < NT && !parts) {
         const int col = 16 * t + c16;
         const float bv = L.b[col];
 #pragma unroll

@@ -60,6 +60,9 @@ struct L1FwdArgs {
   // grid cell, from the device floats [level][HALO_SPLIT] written by knot_halo() every step (see
   // halo_half_width); NULL = fixed grid knots (R = 3)
   const float *halo;
+  // raw != 0: only the spatial part of the pre-activation, sum_k phi_k(s) W0^T[p+k,:] (no bias, no temporal
+  // rows, no LayerNorm/ReLU/Dropout), written to act -- the per-site half of a site x time prediction grid
+  int raw = 0;
 };
 
 // z0 = [X|phi|psi] W0 + b0 -> LN -> ReLU -> Dropout for sorted observations; also writes psi.

@@ -38,7 +38,7 @@ class BasisDesc(C.Structure):
                 ("t_bw", C.c_void_p)]
 
 
-ABI_VERSION = 4            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
+ABI_VERSION = 5            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
 MAX_Q = 8
 LOSS_MSE, LOSS_PINBALL = 0, 1
 
@@ -114,6 +114,13 @@ _SIGNATURES = {
     "stdadk_sparsity_f32": (C.c_int, [C.POINTER(SparsityDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stdadk_spatial_partial_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
+                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32,
+                                             C.c_void_p]),
+    "stdadk_temporal_partial_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
+                                              C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "stdadk_forward_parts_f32": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpTensors), C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "stdadk_train_step_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
                                         C.POINTER(MlpTensors), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_float, C.POINTER(LossDesc),
@@ -425,6 +432,37 @@ def delta_head_backward(delta, dWo, dbo, lambda_grad, lambda_loss, d_delta, loss
                                               lambda_grad, lambda_loss, gptr, _dev(loss_sum, "loss_sum"),
                                               _stream())
     _check(rc, "stdadk_delta_head_backward_f32")
+
+
+def spatial_partial(basis, desc, params, coords, out, workspace, flags):
+    """stdadk_spatial_partial_f32: out (S, h0) = the per-site half of layer 0's pre-activation."""
+    S = coords.shape[0]
+    if tuple(out.shape) != (S, desc.hidden[0]):
+        raise RuntimeError(f"spatial_partial: out has shape {tuple(out.shape)}")
+    rc = lib().stdadk_spatial_partial_f32(C.byref(basis), C.byref(desc), C.byref(params), _dev(coords, "coords"), S,
+                                          _dev(out, "out"), workspace.data_ptr(),
+                                          workspace.numel() * workspace.element_size(), flags, _stream())
+    _check(rc, "stdadk_spatial_partial_f32")
+
+
+def temporal_partial(basis, desc, params, t_values, out, flags):
+    """stdadk_temporal_partial_f32: out (T, h0) = the per-time half of layer 0's pre-activation."""
+    T = t_values.numel()
+    if tuple(out.shape) != (T, desc.hidden[0]):
+        raise RuntimeError(f"temporal_partial: out has shape {tuple(out.shape)}")
+    rc = lib().stdadk_temporal_partial_f32(C.byref(basis), C.byref(desc), C.byref(params), _dev(t_values, "t_values"),
+                                           T, _dev(out, "out"), flags, _stream())
+    _check(rc, "stdadk_temporal_partial_f32")
+
+
+def forward_parts(desc, params, sp, tp, y_pred):
+    """stdadk_forward_parts_f32: y_pred (T*S, Q), rows time-major, from the two halves of layer 0."""
+    S, T = sp.shape[0], tp.shape[0]
+    if y_pred.shape[0] != S * T:
+        raise RuntimeError("forward_parts: y_pred must have T*S rows")
+    rc = lib().stdadk_forward_parts_f32(C.byref(desc), C.byref(params), _dev(sp, "sp"), S, _dev(tp, "tp"), T,
+                                        _dev(y_pred, "y_pred"), _stream())
+    _check(rc, "stdadk_forward_parts_f32")
 
 
 def make_sparsity(kind, lambda_l1=0.01, lambda_group=0.01, apply_spatial=True, apply_temporal=True):

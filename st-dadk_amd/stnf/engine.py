@@ -552,6 +552,38 @@ class Predictor:
         N.forward(st.basis, st.desc, st.params, coords, t, None, B, out, self.ws, st.flags, training=False)
 
     @torch.no_grad()
+    def predict_grid(self, coords, t_values, max_rows=None):
+        """The same S sites at every one of T times (what the reference's dense-grid callers loop over, one
+        model call per time slice): coords (S,2), t_values (T,) -> (T, S, Q).  Layer 0's pre-activation is a
+        per-site row plus a per-time row, so the basis evaluation and the gather of first-layer weights
+        happen once per site; the rest of the network runs on the T*S rows.  Needs the window path (fixed
+        grid knots, compact-support basis) and p = 0; otherwise falls back to predict() on the expanded rows."""
+        st = self.state
+        S, T = coords.shape[0], t_values.numel()
+        coords = coords.contiguous().float()
+        t_values = t_values.contiguous().float().view(-1)
+        Q = self.model.output_dim
+        ok = (self.model.p == 0 and bool(st.flags & N.FLAG_W0_T) and not self.model.spatial_basis.learnable
+              and N.step_uses_window(st.basis, st.desc, st.flags))
+        if not ok or S == 0 or T == 0:
+            cc = coords.repeat(T, 1)
+            tt = t_values.repeat_interleave(S)
+            return self.predict(cc, tt).view(T, S, Q)
+        h0 = self.model.hidden_dims[0]
+        sp = torch.empty(S, h0, device=self.dev)
+        for s0 in range(0, S, self.chunk):
+            n = min(self.chunk, S - s0)
+            N.spatial_partial(st.basis, st.desc, st.params, coords[s0:s0 + n], sp[s0:s0 + n], self.ws, st.flags)
+        tp = torch.empty(T, h0, device=self.dev)
+        N.temporal_partial(st.basis, st.desc, st.params, t_values, tp, st.flags)
+        out = torch.empty(T * S, Q, device=self.dev)
+        per = max(1, (max_rows or (1 << 30)) // max(S, 1))        # time slices per call (int32 row indices)
+        for t0 in range(0, T, per):
+            n = min(per, T - t0)
+            N.forward_parts(st.desc, st.params, sp, tp[t0:t0 + n], out[t0 * S:(t0 + n) * S])
+        return out.view(T, S, Q)
+
+    @torch.no_grad()
     def predict(self, coords, t):
         """coords (N,2), t (N,) or (N,1) on the device -> (N,Q)."""
         if self.model.p != 0:
