@@ -440,7 +440,7 @@ class STInterpMLP(nn.Module):
             tensors[0] = w0.t()                                  # engine-owned (in,out) storage
             flags |= N.FLAG_W0_T
         elif (not force_dense and N.step_uses_window(st.basis, st.desc, flags | N.FLAG_W0_T)) \
-                or self.input_dim <= _DENSE0_MAX_D:
+                or (self.input_dim <= _DENSE0_MAX_D and len(self.hidden_dims) >= 1):
             # window path, or a feature width small enough for the library to run layer 0 inside the tail
             # launch of the materialising path: both want the first weight as (in,out)
             st.keep = w0.t().contiguous()
