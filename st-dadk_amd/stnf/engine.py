@@ -563,17 +563,27 @@ class Predictor:
         coords = coords.contiguous().float()
         t_values = t_values.contiguous().float().view(-1)
         Q = self.model.output_dim
-        ok = (self.model.p == 0 and bool(st.flags & N.FLAG_W0_T) and not self.model.spatial_basis.learnable
-              and N.step_uses_window(st.basis, st.desc, st.flags))
-        if not ok or S == 0 or T == 0:
+        m = self.model
+        parts = m.p == 0 and bool(st.flags & N.FLAG_W0_T) and len(m.hidden_dims) >= 1 and S > 0 and T > 0
+        window = parts and not m.spatial_basis.learnable and N.step_uses_window(st.basis, st.desc, st.flags)
+        if not parts:
             cc = coords.repeat(T, 1)
             tt = t_values.repeat_interleave(S)
             return self.predict(cc, tt).view(T, S, Q)
-        h0 = self.model.hidden_dims[0]
+        h0 = m.hidden_dims[0]
         sp = torch.empty(S, h0, device=self.dev)
-        for s0 in range(0, S, self.chunk):
-            n = min(self.chunk, S - s0)
-            N.spatial_partial(st.basis, st.desc, st.params, coords[s0:s0 + n], sp[s0:s0 + n], self.ws, st.flags)
+        w0t = st.keep if st.keep is not None else m._body[0].weight.detach().t()    # (D, h0), contiguous
+        # sites per call: the workspace's chunk on the window path; about 1 GiB of features on the other
+        step = self.chunk if window else max(1024, min(self.chunk, (1 << 28) // max(m.input_dim, 1)))
+        for s0 in range(0, S, step):
+            n = min(step, S - s0)
+            if window:
+                N.spatial_partial(st.basis, st.desc, st.params, coords[s0:s0 + n], sp[s0:s0 + n], self.ws, st.flags)
+            else:
+                # materialising path (scattered or few knots, Gaussian bases): phi of the chunk's sites, then one
+                # GEMM with the spatial rows of W0^T (p = 0: they are the first k_spatial rows)
+                feats = m.build_features(None, coords[s0:s0 + n], torch.zeros(n, device=self.dev))
+                N.gemm(feats, False, w0t[:m.k_spatial], True, n, h0, m.k_spatial, out=sp[s0:s0 + n])
         tp = torch.empty(T, h0, device=self.dev)
         N.temporal_partial(st.basis, st.desc, st.params, t_values, tp, st.flags)
         out = torch.empty(T * S, Q, device=self.dev)

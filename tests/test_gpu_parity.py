@@ -1701,17 +1701,17 @@ def test_dense_layer0_inside_tail_launch(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name,S,T", [("c2_b257", 1003, 7), ("c2_b257_noln", 64, 1), ("default227", 300, 5),
-                                      ("c2_b257", 70001, 3)])
+                                      ("default227_tri", 2500, 4), ("c2_b257", 70001, 3)])
 def test_predict_grid_equals_row_by_row(name, S, T):
     """Site x time prediction grid: layer 0 as a per-site row + a per-time row (stdadk_spatial_partial_f32,
     stdadk_temporal_partial_f32, stdadk_forward_parts_f32) against the ordinary forward on the expanded T*S
-    rows -- the same sums in another order of addition.  The 227-knot model takes the materialising path,
-    where predict_grid falls back to the ordinary forward."""
+    rows -- the same sums in another order of addition.  The 227-knot models take the materialising path, where
+    the per-site half comes from stdadk_rbf_build_f32 + one GEMM with the spatial rows of W0^T."""
     from stnf.engine import Predictor
     cfg = cases.MODEL_CASES[name]
     d = dev()
     m = build_model(cfg)
-    if name == "default227":
+    if name.startswith("default227"):
         m.force_window_path = False
     m.eval()
     g = torch.Generator().manual_seed(S + T)
