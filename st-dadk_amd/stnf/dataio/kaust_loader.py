@@ -24,7 +24,9 @@ def load_kaust_csv_single(data_path: str, normalize: bool = True) -> Tuple[np.nd
     rows = np.arange(len(df))
     first[site_idx[::-1]] = rows[::-1]
     coords = xy.values[first].astype(np.float32)
-    t_vals = df['t'].values
+    # purely spatial files (KAUST 1a: columns x, y, z) have no time column; the reference reads df['t']
+    # (kaust_loader.py:54) and needs an adapter file with t = 1 for them -- here they load as one time slice
+    t_vals = df['t'].values if 't' in df.columns else np.ones(len(df), dtype=np.int64)
     T = int(t_vals.max())
     print(f"[INFO] Time range: 1 ~ {T}")
     z_data = np.full((T, S), np.nan, dtype=np.float32)

@@ -183,6 +183,11 @@ def test_kaust_loader(tmp_path):
     vals = np.array([1, 2, 3, 5], dtype=np.float32)
     assert abs(md["z_mean"] - vals.mean()) < 1e-6 and abs(md["z_std"] - vals.std()) < 1e-6
     assert abs(zn[0, 0] - (1 - vals.mean()) / vals.std()) < 1e-6
+    # a purely spatial file (KAUST 1a layout: no t column) is one time slice
+    q = tmp_path / "s.csv"
+    q.write_text("id_train,x,y,z\n0,0.5,0.25,1.0\n1,0.1,0.9,2.0\n2,0.7,0.7,5.0\n")
+    z1, c1, _ = load_kaust_csv_single(str(q), normalize=False)
+    assert z1.shape == (1, 3) and np.allclose(z1[0], [1, 2, 5]) and c1.shape == (3, 2)
 
 
 def test_ema_and_metrics_host_logic():
