@@ -33,7 +33,7 @@ int launch_dw_all(GemmGroup &grp, const L1BwdArgs &a_in, int basis, hipStream_t 
   int rc = gemm_tn_grouped_prepare(grp, &ng);
   if (rc) return rc;
   const int nk = knots_per_wave(a);
-  a.xcd_slots = nk == 2 ? knot_xcd_slots(a.g) : 0;
+  a.xcd_slots = knot_xcd_slots(a.g, a.kpart ? 1 : nk);
   const unsigned grid = a.xcd_slots > 0 ? (unsigned)((ng + 7) & ~7) + 8u * (unsigned)a.xcd_slots
                                         : (unsigned)ng + (unsigned)ceil_div(knot_group_count(a.g, nk), BW_T / 64);
 #define GO(CPL_, BS_)                                                                                      \

@@ -32,8 +32,25 @@ __device__ __forceinline__ void l1_window_bwd_body(const L1BwdArgs &a, const int
   __shared__ int lidx[BW_T / 64][BW_LIST + 8];
   __shared__ float lq[KNOTS ? 3 : 1][BW_T / 64][KNOTS ? BW_LIST + 8 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = block * (BW_T / 64) + wave;           // knots in table order: level 0 (coarsest) first
-  if (k >= a.g.Ks) return;
+  int k;
+  if (a.xcd_slots > 0) {
+    // XCD-striped order (see l1_window_bwd_multi_body): XCD block & 7 owns the grid rows [x side/8, (x+1) side/8)
+    // of every level
+    const int x = block & 7;
+    int q = (block >> 3) * (BW_T / 64) + wave, l = 0, r0 = 0;
+    for (; l < a.g.n_levels; ++l) {
+      const int side = a.g.side[l];
+      r0 = (x * side) >> 3;
+      const int np = ((((x + 1) * side) >> 3) - r0) * side;
+      if (q < np) break;
+      q -= np;
+    }
+    if (l >= a.g.n_levels) return;
+    k = a.g.off[l] + r0 * a.g.side[l] + q;            // q = (ix - r0) * side + iy
+  } else {
+    k = block * (BW_T / 64) + wave;                   // knots in table order: level 0 (coarsest) first
+    if (k >= a.g.Ks) return;
+  }
   float *my_phi = lphi[wave];
   int *my_idx = lidx[wave];
   const float kcx = a.g.centers[2 * k], kcy = a.g.centers[2 * k + 1];

@@ -71,7 +71,7 @@ bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt);
 struct L1BwdArgs;
 int knot_group_count(const GridView &g, int nk);  // groups of the per-knot gather of dW0^T, nk knots per wave
 int knots_per_wave(const L1BwdArgs &a);
-int knot_xcd_slots(const GridView &g);            // workgroups per XCD of the XCD-striped pair order, 0 = off
+int knot_xcd_slots(const GridView &g, int nk);    // workgroups per XCD of the XCD-striped group order, 0 = off
 
 struct L1BwdArgs {
   GridView g;

@@ -466,17 +466,17 @@ int knot_group_count(const GridView &g, int nk) {
   return n;
 }
 
-// XCD-striped order of the pair groups: workgroups per XCD = the longest of the eight lists (equal when every
+// XCD-striped order of the knot groups (nk = 1 or 2 knots per wave): workgroups per XCD = the longest of the eight lists (equal when every
 // side is a multiple of 8); environment STDADK_KNOT_XCD=0 switches the striping off (diagnostic)
-int knot_xcd_slots(const GridView &g) {
+int knot_xcd_slots(const GridView &g, int nk) {
   const char *e = getenv("STDADK_KNOT_XCD");
-  if (e && e[0] == '0') return 0;
+  if ((e && e[0] == '0') || (nk != 1 && nk != 2)) return 0;
   int most = 0;
   for (int x = 0; x < 8; ++x) {
     int n = 0;
     for (int l = 0; l < g.n_levels; ++l) {
       const int side = g.side[l];
-      n += ((((x + 1) * side) >> 3) - ((x * side) >> 3)) * ((side + 1) / 2);
+      n += ((((x + 1) * side) >> 3) - ((x * side) >> 3)) * (nk == 2 ? (side + 1) / 2 : side);
     }
     most = n > most ? n : most;
   }
@@ -501,7 +501,7 @@ int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st) {
   STDADK_REQUIRE(a.G <= 256, STDADK_E_ARG, "l1_window_backward: G too large");
   STDADK_REQUIRE((int64_t)a.B * a.H < (1ll << 32), STDADK_E_ARG, "l1_window_backward: B*H exceeds 32-bit offsets");
   const int nk = knots_per_wave(a);
-  a.xcd_slots = nk == 2 ? knot_xcd_slots(a.g) : 0;
+  a.xcd_slots = knot_xcd_slots(a.g, nk);
   const unsigned grid = a.xcd_slots > 0 ? 8u * (unsigned)a.xcd_slots
                                         : (unsigned)ceil_div(knot_group_count(a.g, nk), BW_T / 64);
   STDADK_REQUIRE(!a.kpart || a.W0T, STDADK_E_ARG, "l1_window_backward: knot sums need W0^T");
