@@ -48,3 +48,27 @@ def clip_coefficient(flat_grad, max_norm):
         return 1.0
     total = float(torch.linalg.vector_norm(flat_grad.double()))
     return min(1.0, max_norm / (total + 1e-6))
+
+
+def sharded_predict_grid(predict_grid, coords, t_values, group=None):
+    """Dense prediction grid over several GPUs (BASELINE config C5): the rows are independent, so every rank
+    evaluates its contiguous shard of the SITES at all times with `predict_grid(coords_shard, t_values)`
+    -> (T, S_r, Q) (Predictor.predict_grid) and the shards are all-gathered into (T, S, Q) on every rank.
+    Ragged shards (S not a multiple of the world size) are padded to the longest for the collective."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return predict_grid(coords, t_values)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    S = coords.shape[0]
+    lo, hi = shard_range(S, rank, world)
+    local = predict_grid(coords[lo:hi], t_values)                   # (T, hi - lo, Q)
+    T, Q = local.shape[0], local.shape[2]
+    longest = shard_range(S, 0, world)[1]                           # rank 0 owns one of the longest shards
+    pad = torch.zeros(T, longest, Q, dtype=local.dtype, device=local.device)
+    pad[:, :hi - lo] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.empty(T, S, Q, dtype=local.dtype, device=local.device)
+    for r in range(world):
+        a, b = shard_range(S, r, world)
+        out[:, a:b] = parts[r][:, :b - a]
+    return out

@@ -79,3 +79,41 @@ def test_shard_range_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grid_worker(rank, world, port, S, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "st-dadk_amd"))
+    from stnf import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1)
+        coords = torch.rand(S, 2)
+        tv = torch.linspace(0, 1, 5)
+        # stand-in for Predictor.predict_grid: any row-independent function of (site, time), two outputs
+        fn = lambda c, t: torch.stack([torch.sin(3 * c[:, 0])[None, :] * (1 + t[:, None]),
+                                       (c[:, 1] ** 2)[None, :] - t[:, None]], -1)
+        out = D.sharded_predict_grid(fn, coords, tv)
+        assert out.shape == (5, S, 2) and torch.equal(out, fn(coords, tv))
+        q.put((rank, float(out.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [64, 101, 1])            # 101, 1 => ragged / empty shards
+def test_sharded_prediction_grid_gloo(S):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grid_worker, args=(r, world, port, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert abs(res[0][1] - res[1][1]) < 1e-9
