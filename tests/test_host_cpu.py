@@ -326,3 +326,15 @@ def test_spatial_metrics_and_print(capsys):
     print_metrics(compute_metrics(np.array([1.0, 2.0, 3.0]), np.array([1.0, 2.0, 4.0])), prefix="Val")
     out = capsys.readouterr().out
     assert out.startswith("Val Metrics:") and "RMSE: 0.577350" in out and "R²:" in out
+
+
+def test_public_header_is_plain_c():
+    """include/stdadk.h is the drop-in boundary: it must parse as C99 and as C++ on its own (no torch / HIP types)."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "stdadk.h")
+    for cc, args in (("gcc", ["-std=c99", "-x", "c"]), ("g++", ["-std=c++11", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not available")
+        r = subprocess.run([cc, *args, "-fsyntax-only", "-Wall", "-Werror", hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
