@@ -285,7 +285,8 @@ def main():
                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                         "avg_launch_us": avg_us, "algorithmic_flops_per_launch": amount}
             tr_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tr_file):           # HBM bytes/launch from rocprofv3 --pmc (committed summary)
+            # HBM bytes/launch from rocprofv3 --pmc (committed summary, measured at the default C2 / B = 4096 shape)
+            if os.path.exists(tr_file) and args.workload == "c2" and B == 4096:
                 try:
                     tj = json.load(open(tr_file))
                     for key, val in tj.get("kernels", {}).items():
@@ -301,6 +302,13 @@ def main():
                                                 feats), 50)
         rbf_bytes = B * (12 + 4 * D)                         # 12 B read + 4*D written / obs
         rbf_gbs = rbf_bytes / t_rbf / 1e9
+        rbf_traffic = None                                   # HBM bytes/launch from the committed PMC summary
+        try:                                                 # (measured at the default C2 / B = 4096 shape only)
+            if args.workload == "c2" and B == 4096:
+                rbf_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(
+                    "rbf_build_kernel")
+        except Exception:
+            pass
         out = {
             "metric": "train-step samples/sec (obs points/sec)", "value": args.gpus * B * args.steps / el,
             "unit": "obs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -318,7 +326,7 @@ def main():
             "roofline": roof,
             "rbf_build": {"bound": "hbm", "achieved": rbf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": rbf_gbs / HBM_PEAK_GBS, "bytes_per_obs": 12 + 4 * D, "avg_launch_us": t_rbf * 1e6,
-                          "traffic": None, "note": "one launch of stdadk_rbf_build_f32 over all column tiles"},
+                          "traffic": rbf_traffic, "note": "one launch of stdadk_rbf_build_f32 over all column tiles"},
             "kernels_us_per_step": kernels_us,
             "kernel_time_us_per_step": round(sum(r[3] for r in per_step), 1),
             "nonzero_obs_knot_pairs_per_obs": nnz / B,
