@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STDADK_ABI_VERSION 5
+#define STDADK_ABI_VERSION 6
 #define STDADK_MAX_HIDDEN 8
 #define STDADK_MAX_LEVELS 8
 #define STDADK_SUMSQ_PARTS 256 /* partial sums written by stdadk_sumsq_f32 */
@@ -311,6 +311,17 @@ int stdadk_knot_backward_f32(const stdadk_basis_desc *basis, const stdadk_mlp_de
                              void *workspace, size_t workspace_bytes, int32_t flags,
                              const stdadk_knot_train *kt, float *d_centers, float *d_log_bw,
                              float *loss_sum, stdadk_stream_t stream);
+
+/* N2 at module level: the backward of SpatialBasisEmbedding.forward (st_interp.py:433-460) on its own, for callers
+ * that differentiate through `model.spatial_basis(coords)` directly rather than through STInterpMLP.forward:
+ * d_phi [B, ld] = dLoss/dphi (column k <-> knot k), centres [Ks,2], LOG-bandwidths [Ks] ->
+ *   d_centers[k] = sum_b d_phi[b,k] phi'(r) (-(x-c_k)/(|x-c_k| s_k)),  d_log_bw[k] = sum_b d_phi[b,k] phi'(r) (-r)
+ * (both overwritten; no damping hook, no penalties: those stay with the caller's autograd). */
+size_t stdadk_knot_grad_workspace_bytes(int64_t B, int64_t Ks);
+int stdadk_knot_grad_f32(const float *coords, int64_t B, const float *d_phi, int64_t ld,
+                         const float *centers, const float *log_bw, int64_t Ks, int32_t basis,
+                         float *d_centers, float *d_log_bw, void *workspace, size_t workspace_bytes,
+                         stdadk_stream_t stream);
 
 /* A2-A8 in one call: training forward, the batch objective and its gradient, backward:
  *   loss == NULL (nn.MSELoss): loss_sum[0] += sum((y_pred-y)^2), grads = d/dparams of

@@ -152,3 +152,44 @@ int launch_knot_finish(const KnotFinishArgs &a, hipStream_t st) {
 }
 
 }  // namespace stdadk
+
+// ---------------------------------------------------------------------------------------------------------
+// Module-level autograd of SpatialBasisEmbedding.forward with learnable knots: dL/dphi in, knot gradients out
+// ---------------------------------------------------------------------------------------------------------
+using namespace stdadk;
+
+extern "C" size_t stdadk_knot_grad_workspace_bytes(int64_t B, int64_t Ks) {
+  if (B < 0 || Ks < 0) return 0;
+  const size_t slabs = (size_t)knot_slabs(B > 0 ? B : 1);
+  return (align_up((size_t)(Ks > 0 ? Ks : 1), 64) + align_up(slabs * 3 * (size_t)(Ks > 0 ? Ks : 1), 64)) * sizeof(float);
+}
+
+extern "C" int stdadk_knot_grad_f32(const float *coords, int64_t B, const float *d_phi, int64_t ld,
+                                    const float *centers, const float *log_bw, int64_t Ks, int32_t basis,
+                                    float *d_centers, float *d_log_bw, void *workspace, size_t workspace_bytes,
+                                    stdadk_stream_t stream) {
+  STDADK_REQUIRE(B >= 0 && B < (1ll << 31) && Ks >= 0 && Ks < (1ll << 31) && basis >= 0 && basis <= 2, STDADK_E_ARG,
+                 "knot_grad: bad sizes / basis");
+  if (Ks == 0) return 0;
+  STDADK_REQUIRE(centers && log_bw && d_centers && d_log_bw, STDADK_E_ARG, "knot_grad: NULL pointer");
+  STDADK_REQUIRE(B == 0 || (coords && d_phi && ld >= Ks), STDADK_E_ARG, "knot_grad: NULL batch pointer or ld < Ks");
+  STDADK_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= stdadk_knot_grad_workspace_bytes(B, Ks),
+                 STDADK_E_WORKSPACE, "knot_grad: workspace NULL, unaligned or smaller than stdadk_knot_grad_workspace_bytes");
+  hipStream_t st = (hipStream_t)stream;
+  float *bw = (float *)workspace;
+  float *part = bw + align_up((size_t)Ks, 64);
+  int rc = launch_exp(log_bw, Ks, bw, st);
+  if (rc) return rc;
+  KnotFinishArgs fa;
+  fa.part = part; fa.slabs = B > 0 ? knot_slabs(B) : 0; fa.Ks = (int)Ks; fa.centers = centers; fa.centers_init = nullptr;
+  fa.damping = 0; fa.thr = fa.strength = 0.f; fa.dom_w = fa.mov_w = 0.f; fa.pen_grad_scale = fa.pen_loss_scale = 0.f;
+  fa.d_centers = d_centers; fa.d_log_bw = d_log_bw; fa.loss_sum = nullptr;
+  if (B > 0) {
+    KnotGradArgs ka;
+    ka.coords = coords; ka.B = (int)B; ka.dFeat = d_phi; ka.ld = ld; ka.p = 0;
+    ka.centers = centers; ka.bw = bw; ka.Ks = (int)Ks; ka.basis = basis; ka.part = part; ka.slabs = fa.slabs;
+    rc = launch_knot_grad(ka, st);
+    if (rc) return rc;
+  }
+  return launch_knot_finish(fa, st);       // B == 0: no slabs, the gradients come out as zeros
+}

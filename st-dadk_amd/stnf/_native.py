@@ -38,7 +38,7 @@ class BasisDesc(C.Structure):
                 ("t_bw", C.c_void_p)]
 
 
-ABI_VERSION = 5            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
+ABI_VERSION = 6            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
 MAX_Q = 8
 LOSS_MSE, LOSS_PINBALL = 0, 1
 
@@ -145,6 +145,10 @@ _SIGNATURES = {
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int32,
                                            C.POINTER(KnotTrain), C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
+    "stdadk_knot_grad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "stdadk_knot_grad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p]),
     "stdadk_train_fwd_bwd_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc),
                                            C.POINTER(MlpTensors), C.POINTER(MlpTensors), C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
@@ -223,10 +227,15 @@ def _dev(tensor, name):
         raise RuntimeError(f"{name}: unsupported dtype {tensor.dtype}")
     if not tensor.is_contiguous():
         raise RuntimeError(f"{name}: tensor must be contiguous")
+    if tensor.device.index != torch.cuda.current_device():
+        # the launch stream is the CURRENT device's current stream (_stream below)
+        raise RuntimeError(f"{name}: tensor lives on {tensor.device} but the current device is cuda:"
+                           f"{torch.cuda.current_device()}; call under torch.cuda.device({tensor.device.index})")
     return tensor.data_ptr()
 
 
 def _stream():
+    """The current HIP stream of the current device (every tensor of a call is checked to live there)."""
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -553,6 +562,20 @@ def knot_backward(basis, desc, params, coords, B, workspace, flags, knot_train, 
                                         _dev(d_centers, "d_centers"), _dev(d_log_bw, "d_log_bw"),
                                         _dev(loss_sum, "loss_sum"), _stream())
     _check(rc, "stdadk_knot_backward_f32")
+
+
+def knot_grad(coords, d_phi, centers, log_bw, basis, d_centers, d_log_bw):
+    """stdadk_knot_grad_f32: dL/dphi (B, Ks) -> gradients w.r.t. the centres (Ks,2) and log-bandwidths (Ks,)."""
+    B, Ks = d_phi.shape
+    if d_phi.stride(1) != 1:
+        raise RuntimeError("knot_grad: d_phi must have unit column stride")
+    need = lib().stdadk_knot_grad_workspace_bytes(B, Ks)
+    ws = torch.empty(max(need // 4, 1), device=d_phi.device, dtype=torch.float32)
+    rc = lib().stdadk_knot_grad_f32(_dev(coords, "coords"), B, d_phi.data_ptr(), d_phi.stride(0),
+                                    _dev(centers, "centers"), _dev(log_bw, "log_bw"), Ks, BASIS_KIND[basis],
+                                    _dev(d_centers, "d_centers"), _dev(d_log_bw, "d_log_bw"), ws.data_ptr(),
+                                    ws.numel() * 4, _stream())
+    _check(rc, "stdadk_knot_grad_f32")
 
 
 def gather_batch(coords, t, y, X, idx, coords_out, t_out, y_out, X_out):

@@ -38,7 +38,12 @@ class DeviceDataset:
         return self.n
 
     def epoch_batches(self, batch_size, generator=None, shuffle=True):
-        """Index slices of one epoch (last one ragged, like DataLoader without drop_last)."""
+        """Index slices of one epoch (last one ragged, like DataLoader without drop_last).  `batch_size` may be
+        a list of sizes summing to len(self) (the data-parallel schedule of stnf.distributed.epoch_schedule)."""
         dev = self.coords.device
         idx = torch.randperm(self.n, device=dev, generator=generator) if shuffle else torch.arange(self.n, device=dev)
+        if not isinstance(batch_size, int):
+            batch_size = [int(b) for b in batch_size]
+            if sum(batch_size) != self.n:
+                raise ValueError(f"batch sizes sum to {sum(batch_size)}, the set has {self.n} rows")
         return idx.split(batch_size)

@@ -6,8 +6,10 @@ Every rank holds the full model (<= 51 MB) and its own shard of the observations
      its gradient is its share of the global-batch mean (nn.MSELoss over the union of the shards);
   2. ONE all-reduce (SUM) of the flat fp32 gradient buffer;
   3. the clip norm is taken from the reduced gradient, AdamW/EMA run replicated.
-A ragged last batch needs no special case: grad_scale carries the global row count
-(SURVEY.md §7 "DDP equivalence").  These helpers are backend-agnostic (`nccl` = RCCL on the GPUs,
+A ragged batch needs no special case in the arithmetic: grad_scale carries the global row count
+(SURVEY.md §7 "DDP equivalence").  What ragged SHARDS need is a common step count: `epoch_schedule` fixes it
+(and every step's global row count) on the host from one all-gather of the shard sizes, so no rank ever
+waits in a collective its partners do not enter.  These helpers are backend-agnostic (`nccl` = RCCL on the GPUs,
 `gloo` in the CPU tests).
 """
 import torch
@@ -28,6 +30,50 @@ def global_rows(local_rows, group=None, device=None):
     t = torch.tensor([int(local_rows)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return int(t.item())
+
+
+def gather_shard_sizes(local_rows, group=None, device=None):
+    """Row count of every rank's shard, identical on all ranks: ONE all-gather per data set (not per step)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [int(local_rows)]
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(local_rows)], dtype=torch.int64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return [int(p.item()) for p in parts]
+
+
+def _rank_batches(n, batch_size, steps):
+    """Batch sizes of one rank's epoch in exactly `steps` non-empty batches.  Full batches with a ragged last one
+    (a DataLoader without drop_last, scripts/train_st_interp.py:2295-2301) whenever that already takes `steps`
+    batches; a rank that would finish one step early hands one row of its last full batch to an extra batch; a
+    rank with far fewer rows than the longest shard splits its rows evenly."""
+    if n < steps:
+        raise RuntimeError(f"a shard of {n} rows cannot take part in {steps} steps; give every rank at least as "
+                           f"many rows as the longest shard has batches")
+    full, rem = divmod(n, batch_size)
+    own = full + (1 if rem else 0)
+    if own == steps:
+        return [batch_size] * full + ([rem] if rem else [])
+    if own == steps - 1 and rem == 0:
+        return [batch_size] * (full - 1) + [batch_size - 1, 1]
+    base, extra = divmod(n, steps)
+    return [base + 1] * extra + [base] * (steps - extra)
+
+
+def epoch_schedule(shard_sizes, batch_size):
+    """Collective-safe epoch plan for observation-sharded training, computed on the host from the gathered
+    shard sizes (every rank computes the same table): returns sizes[step][rank].  Every rank runs the same
+    number of steps (ceil(longest shard / batch)) with a non-empty batch in each, so the per-step gradient
+    all-reduce always meets its partners, and a step's global row count is sum(sizes[step]) with no
+    per-step collective."""
+    if batch_size < 1:
+        raise ValueError("batch_size must be >= 1")
+    if not shard_sizes or max(shard_sizes) == 0:
+        return []
+    steps = -(-max(shard_sizes) // batch_size)
+    per_rank = [_rank_batches(n, batch_size, steps) for n in shard_sizes]
+    return [[per_rank[r][i] for r in range(len(shard_sizes))] for i in range(steps)]
 
 
 def grad_scale(global_row_count, out_dim):

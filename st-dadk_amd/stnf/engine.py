@@ -54,6 +54,12 @@ def flatten_parameters(model, transpose_first=True):
     return flat, offs
 
 
+def _rank_seed(base, rank):
+    """Dropout seed of one rank: the base seed with the rank mixed in (an odd 64-bit multiplier, so different
+    ranks never share a (seed, step, layer, element) stream)."""
+    return (int(base) + 0xD1B54A32D192ED03 * int(rank)) & 0xFFFFFFFFFFFFFFFF
+
+
 def _wait(stream, ev):
     if isinstance(ev, _LightEvent):
         import ctypes
@@ -88,6 +94,21 @@ class _LightEvent:
         self.recorded = True
 
 
+_FORCE_TORCH_EVENTS = False     # tests: take the torch.cuda.Event branch of _event_factory
+
+
+def _event_factory():
+    """_LightEvent when the HIP runtime can be reached through ctypes, else torch.cuda.Event (same ordering
+    semantics, a system-scope fence per record)."""
+    if _FORCE_TORCH_EVENTS:
+        return torch.cuda.Event
+    try:
+        _LightEvent()
+        return _LightEvent
+    except (OSError, RuntimeError, AttributeError):
+        return torch.cuda.Event
+
+
 class TrainStep:
     """One fused optimisation step of STInterpMLP (fixed or learnable knots).
 
@@ -116,7 +137,7 @@ class TrainStep:
                  non_crossing_lambda=0.0, basis_lr_ratio=0.05, basis_clip_ratio=0.1,
                  domain_penalty_weight=0.0, movement_penalty_weight=0.0, sparsity_penalty_type="none",
                  sparsity_lambda_l1=0.001, sparsity_lambda_group=0.01, sparsity_apply_to_spatial=True,
-                 sparsity_apply_to_temporal=True):
+                 sparsity_apply_to_temporal=True, seed=None, world_size=None):
         self.model = model
         if loss not in ("mse", "pinball"):
             raise ValueError(f"unknown loss '{loss}'; use 'mse' or 'pinball'")
@@ -205,7 +226,10 @@ class TrainStep:
         self.sumsq = torch.zeros(N.SUMSQ_PARTS, device=self.dev)
         self.lr_dev = torch.full((1,), self.lr, device=self.dev)
         self.step_dev = torch.zeros(1, device=self.dev, dtype=torch.int32)
-        self.seed = 0x5DEECE66D
+        # dropout stream: the base seed comes from torch's generator (so `set_seed` / torch.manual_seed decide
+        # it, as they decide nn.Dropout's masks in the reference) unless given; the rank is mixed in below so
+        # that the shards of a data-parallel batch draw independent masks
+        self.base_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         # optional: independent kernels of a step fork onto this stream (fork/join inside the library).
         # Measured on MI355X at B = 4096: no gain eager, 12 % SLOWER under hipGraph replay (cross-stream
         # edges cost more than the overlap of ~20 us kernels buys), hence off by default.
@@ -217,6 +241,12 @@ class TrainStep:
         self.distributed = bool(distributed)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.rank = dist.get_rank(process_group) if self.distributed else 0
+        if world_size is not None:
+            # tests: this engine plays one of `world_size` ranks whose gradients the caller sums itself
+            # (split path, 1/world shares of the parameter-level penalties); see set_virtual_rank
+            self.world = int(world_size)
+        self.seed = _rank_seed(self.base_seed, self.rank)
         # graph
         self.use_graph = bool(use_graph)
         self._graph = None
@@ -227,12 +257,15 @@ class TrainStep:
         self._ix_graph = None
         # the one-call step applies with a single parameter group on one GPU (data-parallel training needs
         # the all-reduce between backward and optimiser; learnable knots / the delta head have extra kernels there)
-        self._whole_step = (not self.distributed and not self.learnable and not model._has_delta
-                            and self.aux_stream is None)
+        self._whole_step = (not self.distributed and self.world == 1 and not self.learnable
+                            and not model._has_delta and self.aux_stream is None)
         self._optim = None
         self._sumsq512 = torch.zeros(N.GRADSQ_PARTS, device=self.dev)
         self._pipe = None          # two workspaces + side stream of the pipelined batch preparation
         self._prepared = None      # ((idx data_ptr, numel), workspace index, idx tensor) of the announced batch
+        self.time_allreduce = False   # bench: bracket the gradient all-reduce with timing events
+        self.allreduce_events = []
+        self._sched = None         # run_epoch under data parallelism: (dataset key, per-step per-rank batch sizes)
 
     # ------------------------------------------------------------------------------------
     def set_lr(self, lr):
@@ -267,9 +300,37 @@ class TrainStep:
                          self._optim, seed=self.seed, loss_desc=self._loss_desc(y.shape[1]),
                          sparsity_desc=self._sparsity)
             return
+        self._enqueue_grads(X, coords, t, y, B, global_rows, idx=idx, ws=ws, prebinned=prebinned)
+        if self.distributed:
+            if self.time_allreduce:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                D.allreduce_gradients(self.grad, self.pg)
+                e1.record()
+                self.allreduce_events.append((e0, e1))
+            else:
+                D.allreduce_gradients(self.grad, self.pg)
+        self._enqueue_optimizer()
+
+    def _enqueue_grads(self, X, coords, t, y, B, global_rows, idx=None, ws=None, prebinned=False):
+        """Split path, first half: this rank's share of the global-batch gradient into `self.grad` (every
+        tensor overwritten) and of the objective into `self.loss_sum`.  d(mean over the GLOBAL batch)/dparams:
+        each rank scales by 1/global_rows and adds 1/world of the parameter-level penalty gradients, so the
+        SUM over ranks is the gradient of the single-process objective on the union batch."""
+        st = self.state
+        ws = self.ws if ws is None else ws
+        flags = st.flags | (N.FLAG_PREBINNED if prebinned else 0)
+        Q = self.model.output_dim
+        if B == 0:
+            # a rank without rows in this step (possible only with caller-made batches; run_epoch's schedule
+            # never produces one): no data term; the penalty shares below need a batch's backward state
+            if self.learnable or self._sparsity is not None or (st.head is not None and self.nc_lambda != 0.0):
+                raise RuntimeError("an empty local batch cannot carry this rank's share of the parameter-level "
+                                   "penalties; use run_epoch's schedule (stnf.distributed.epoch_schedule)")
+            self.grad.zero_()
+            return
         if st.head is not None:
             N.delta_head(st.delta, st.head[0], st.head[1])          # output layer of this step's delta
-        # d(mean over the GLOBAL batch)/dparams: each rank scales by 1/global_rows, the all-reduce SUMs
         if idx is not None and not prebinned:
             N.train_fwd_bwd_indexed(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, idx,
                                     D.grad_scale(global_rows, Q), self.loss_sum, None, ws, flags,
@@ -297,8 +358,10 @@ class TrainStep:
             m = self.model
             N.sparsity(self._sparsity, self._w0t, self._g_w0t, True, m.p, m.k_spatial, m.k_temporal,
                        grad_scale=1.0 / self.world, loss_scale=float(B * Q), loss_sum=self.loss_sum)
-        if self.distributed:
-            D.allreduce_gradients(self.grad, self.pg)
+
+    def _enqueue_optimizer(self):
+        """Split path, second half: clip norm(s) of the (reduced) gradient, AdamW + EMA; advances the device
+        step counter once."""
         ke = self.knot_end
         if ke and self.grad_clip > 0:
             # learnable knots: both groups' clip norms in one launch, both AdamW/EMA updates in one launch
@@ -328,6 +391,12 @@ class TrainStep:
                         self.basis_lr, self.betas, self.eps, self.wd, self.step_count + 1, max_norm=self.basis_clip,
                         sumsq_parts=self.sumsq_basis, ema_decay=self.ema_decay, lr_dev=self.basis_lr_dev,
                         step_dev=self.step_dev)
+
+    def set_virtual_rank(self, rank):
+        """Tests of the data-parallel arithmetic on one GPU: play rank `rank` of `world_size` (dropout stream
+        of that rank; the caller sums the ranks' `grad` buffers between _enqueue_grads and _enqueue_optimizer)."""
+        self.rank = int(rank)
+        self.seed = _rank_seed(self.base_seed, self.rank)
 
     def _loss_desc(self, y_cols):
         """ABI loss descriptor for targets with `y_cols` columns (None = the plain MSE fast path)."""
@@ -360,8 +429,14 @@ class TrainStep:
             self._step_graph(X, coords, t, y, B, global_rows)
         else:
             self._enqueue(X, coords, t, y, B, global_rows)
+        self._stepped(B)
+
+    def _stepped(self, B):
         self.step_count += 1
         self.rows_seen += B
+        # the kernels update the parameters through raw pointers (no autograd version bump): Predictors that
+        # cache derived tensors (the delta head's output layer) watch this counter
+        self.model._engine_version = getattr(self.model, "_engine_version", 0) + 1
 
     def step_indexed(self, coords_all, t_all, y_all, idx, X_all=None, global_rows=None, next_idx=None):
         """One optimisation step on rows `idx` (int64 device tensor) of device-RESIDENT observation
@@ -373,7 +448,9 @@ class TrainStep:
         `next_idx` (window path, eager launch chain): the rows of the FOLLOWING step.  Their gather and
         binning are enqueued on a second stream into a second workspace while this step runs, and the
         following call (same tensor as its `idx`) starts at the layer-0 kernel — batch preparation
-        leaves the critical path.  The index tensors must not be modified in between."""
+        leaves the critical path.  `next_idx` (and the resident arrays) only need to be ENQUEUED on the
+        current stream, not complete: the side stream is ordered behind the current stream's work at the
+        time of this call.  The index tensors must not be modified in between."""
         B = idx.numel()
         if B > self.max_batch:
             raise RuntimeError(f"batch {B} > max_batch {self.max_batch}")
@@ -395,8 +472,7 @@ class TrainStep:
         src = ib if graphed else (idx if idx.is_contiguous() else idx.contiguous())
         if self.uses_window and not graphed and (next_idx is not None or self._prepared is not None):
             self._step_pipelined(coords_all, t_all, y_all, Xa, src, next_idx, B, global_rows)
-            self.step_count += 1
-            self.rows_seen += B
+            self._stepped(B)
             return
 
         def enqueue():
@@ -424,23 +500,31 @@ class TrainStep:
                 self._ix_graph[1].replay()
         else:
             enqueue()
-        self.step_count += 1
-        self.rows_seen += B
+        self._stepped(B)
 
     def run_epoch(self, dataset, batch_size, generator=None, shuffle=True):
         """One pass over a `stnf.dataio.device_dataset.DeviceDataset` in shuffled mini-batches (the
         epoch loop of scripts/train_st_interp.py:608-724 with the set resident in HBM): every step
         announces the next batch so that its preparation overlaps the running step.  Returns the mean
-        batch objective of the epoch (ONE host sync)."""
-        batches = dataset.epoch_batches(batch_size, generator=generator, shuffle=shuffle)
-        world_rows = None
+        batch objective of the epoch (ONE host sync).
+
+        Data-parallel: `dataset` is this rank's shard.  The shard sizes are all-gathered once per data set and
+        `stnf.distributed.epoch_schedule` gives every rank the same number of steps, a non-empty batch in each
+        and each step's global row count -- no per-step collective besides the gradient all-reduce."""
+        if self.distributed:
+            key = (id(dataset), len(dataset), int(batch_size))
+            if self._sched is None or self._sched[0] != key:
+                sizes = D.gather_shard_sizes(len(dataset), self.pg, device=self.dev)
+                self._sched = (key, D.epoch_schedule(sizes, int(batch_size)))
+            table = self._sched[1]
+            batches = dataset.epoch_batches([row[self.rank] for row in table], generator=generator, shuffle=shuffle)
+            rows = [sum(row) for row in table]
+        else:
+            batches = dataset.epoch_batches(batch_size, generator=generator, shuffle=shuffle)
+            rows = [None] * len(batches)
         for i, idx in enumerate(batches):
             nxt = batches[i + 1] if i + 1 < len(batches) else None
-            if self.distributed:
-                # full batches: every rank has batch_size rows; only the ragged last one asks the group
-                world_rows = (idx.numel() * self.world if idx.numel() == batch_size
-                              else D.global_rows(idx.numel(), self.pg, device=self.dev))
-            self.step_indexed(dataset.coords, dataset.t, dataset.y, idx, X_all=dataset.X, global_rows=world_rows,
+            self.step_indexed(dataset.coords, dataset.t, dataset.y, idx, X_all=dataset.X, global_rows=rows[i],
                               next_idx=nxt)
         return self.mean_loss()
 
@@ -451,13 +535,9 @@ class TrainStep:
         if self._pipe is None:
             # events without the system-scope fence (both streams are on this device): 3 us per step
             # cheaper than torch.cuda.Event on MI355X; fall back if the HIP runtime cannot be reached
-            try:
-                _LightEvent()
-                mk = _LightEvent
-            except (OSError, RuntimeError, AttributeError):
-                mk = torch.cuda.Event
+            mk = _event_factory()
             self._pipe = dict(ws=[self.ws, torch.empty_like(self.ws)], stream=torch.cuda.Stream(device=self.dev),
-                              done=[mk(), mk()], binned=mk(), last=1)
+                              announce=mk(), binned=mk(), last=1)
         pp = self._pipe
         st = self.state
         prep = self._prepared
@@ -470,7 +550,11 @@ class TrainStep:
         if next_idx is not None:
             nxt = next_idx if next_idx.is_contiguous() else next_idx.contiguous()
             wsj = 1 - wsi
-            _wait(pp["stream"], pp["done"][wsj])           # the last step that used that workspace is over
+            # the side stream starts after everything enqueued on the main stream so far: the step that last
+            # used that workspace (the previous one), AND whatever produced `next_idx` and the resident arrays
+            # (a device randperm at the start of an epoch is a multi-kernel sort on the main stream)
+            pp["announce"].record(main)
+            _wait(pp["stream"], pp["announce"])
             with torch.cuda.stream(pp["stream"]):
                 N.bin_batch(st.basis, st.desc, coords_all, t_all, Xa, y_all, nxt, pp["ws"][wsj], st.flags)
                 pp["binned"].record(pp["stream"])
@@ -479,7 +563,6 @@ class TrainStep:
             self._enqueue(None, None, None, y_all, B, global_rows, ws=pp["ws"][wsi], prebinned=True)
         else:
             self._enqueue(Xa, coords_all, t_all, y_all, B, global_rows, idx=idx, ws=pp["ws"][wsi])
-        pp["done"][wsi].record(main)
         pp["last"] = wsi
 
     def _step_graph(self, X, coords, t, y, B, global_rows):
@@ -525,6 +608,7 @@ class TrainStep:
         tmp = self.flat.clone()
         self.flat.copy_(self.ema)
         self.ema.copy_(tmp)
+        self.model._engine_version = getattr(self.model, "_engine_version", 0) + 1
 
 
 class Predictor:
@@ -538,7 +622,9 @@ class Predictor:
         self.model = model
         self.dev = next(model.parameters()).device
         self.chunk = int(chunk)
+        self.force_dense = force_dense
         self.state = model._step_state(self.dev, force_dense=force_dense, training=False)
+        self._state_key = self._param_key()
         self.ws = torch.empty(N.step_workspace_bytes(self.state.basis, self.state.desc, self.chunk,
                                                      self.state.flags) // 4, device=self.dev)
         self.use_graph = use_graph
@@ -546,6 +632,23 @@ class Predictor:
         self._warm = False
         self._in = (torch.empty(self.chunk, 2, device=self.dev), torch.empty(self.chunk, device=self.dev))
         self._out = torch.empty(self.chunk, model.output_dim, device=self.dev)
+
+    def _param_key(self):
+        """Identity + version of everything the cached state was derived from: parameter storage (a TrainStep
+        built later re-points it), autograd versions (optimizer.step(), load_state_dict, EMA swaps through
+        copy_) and the engine's step counter (its kernels write through raw pointers)."""
+        m = self.model
+        return (getattr(m, "_engine_version", 0),) + tuple((p.data_ptr(), p._version) for p in m.parameters()) \
+            + tuple((b.data_ptr(), b._version) for b in m.buffers())
+
+    def _refresh(self):
+        """Rebuild the descriptors when the model changed since they were made (stale transposed copy of W0,
+        stale output layer of the delta head, re-pointed parameter storage); a captured graph is dropped."""
+        key = self._param_key()
+        if key != self._state_key:
+            self.state = self.model._step_state(self.dev, force_dense=self.force_dense, training=False)
+            self._state_key = key
+            self._graph = None
 
     def _enqueue(self, coords, t, out, B):
         st = self.state
@@ -558,6 +661,7 @@ class Predictor:
         per-site row plus a per-time row, so the basis evaluation and the gather of first-layer weights
         happen once per site; the rest of the network runs on the T*S rows.  Needs the window path (fixed
         grid knots, compact-support basis) and p = 0; otherwise falls back to predict() on the expanded rows."""
+        self._refresh()
         st = self.state
         S, T = coords.shape[0], t_values.numel()
         coords = coords.contiguous().float()
@@ -598,6 +702,7 @@ class Predictor:
         """coords (N,2), t (N,) or (N,1) on the device -> (N,Q)."""
         if self.model.p != 0:
             raise RuntimeError("Predictor: covariates (p>0) are not wired into the dense-grid path")
+        self._refresh()
         n = coords.shape[0]
         coords = coords.contiguous().float()
         t = t.contiguous().float().view(-1)

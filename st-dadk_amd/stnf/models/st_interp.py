@@ -29,6 +29,28 @@ def _round_up(a, b):
     return (a + b - 1) // b * b
 
 
+class _PhiFunction(torch.autograd.Function):
+    """phi(coords; centres, log-bandwidths) with the knot gradients of stdadk_knot_grad_f32 (module-level autograd
+    of SpatialBasisEmbedding.forward, reference :433-460; no gradient flows into the coordinates)."""
+
+    @staticmethod
+    def forward(ctx, coords, centers, log_bw, basis):
+        out = torch.empty(coords.shape[0], centers.shape[0], device=coords.device, dtype=torch.float32)
+        N.rbf_build(coords, None, None, centers.detach().contiguous(), torch.exp(log_bw.detach()).contiguous(), basis,
+                    None, None, out)
+        ctx.save_for_backward(coords, centers, log_bw)
+        ctx.basis = basis
+        return out
+
+    @staticmethod
+    def backward(ctx, d_phi):
+        coords, centers, log_bw = ctx.saved_tensors
+        dc, dlb = torch.empty_like(centers, memory_format=torch.contiguous_format), torch.empty_like(log_bw)
+        N.knot_grad(coords, d_phi.contiguous().float(), centers.detach().contiguous(), log_bw.detach().contiguous(),
+                    ctx.basis, dc, dlb)
+        return None, dc, dlb, None
+
+
 class SpatialBasisEmbedding(nn.Module):
     """Multi-resolution 2-D radial basis phi(s) over fixed knot grids (reference :18-546)."""
 
@@ -155,10 +177,13 @@ class SpatialBasisEmbedding(nn.Module):
             b, n, _ = coords.shape
             coords, squeeze = coords.reshape(b * n, 2), (b, n)
         coords = coords.contiguous().float()
-        out = torch.empty(coords.shape[0], self.k, device=coords.device, dtype=torch.float32)
-        # (values only: gradients into learnable knots flow through STInterpMLP.forward)
-        N.rbf_build(coords, None, None, self.centers.detach(), self.bandwidths.detach(), self.basis_function,
-                    None, None, out)
+        if self.learnable and torch.is_grad_enabled() and (self.centers.requires_grad or self.log_bandwidths.requires_grad):
+            # differentiable w.r.t. the knots, as the reference's module is (its forward is plain autograd ops)
+            out = _PhiFunction.apply(coords, self.centers, self.log_bandwidths, self.basis_function)
+        else:
+            out = torch.empty(coords.shape[0], self.k, device=coords.device, dtype=torch.float32)
+            N.rbf_build(coords, None, None, self.centers.detach(), self.bandwidths.detach(), self.basis_function,
+                        None, None, out)
         return out.view(*squeeze, self.k) if squeeze else out
 
     def compute_domain_penalty(self, domain_bounds=(0.0, 1.0)):

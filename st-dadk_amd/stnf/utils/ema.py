@@ -28,15 +28,21 @@ class ModelEMA:
             torch._foreach_lerp_(shadows, params, 1.0 - self.decay)
 
     def apply_shadow(self):
-        for n, p in self.model.named_parameters():
-            if p.requires_grad:
-                self.backup[n] = p.data.clone()
-                p.data = self.shadow[n]
+        """Swap the EMA weights in for validation (reference ema.py:68-77).  The values are copied INTO the
+        parameters' existing storage: a parameter may be a view of an engine's flat buffer (stnf.engine), and
+        rebinding `.data` would silently detach it from the buffer the fused kernels train."""
+        with torch.no_grad():
+            for n, p in self.model.named_parameters():
+                if p.requires_grad:
+                    self.backup[n] = p.data.clone()
+                    p.data.copy_(self.shadow[n])
 
     def restore(self):
-        for n, p in self.model.named_parameters():
-            if p.requires_grad:
-                p.data = self.backup[n]
+        """Put the training weights back (reference ema.py:79-89), again in place."""
+        with torch.no_grad():
+            for n, p in self.model.named_parameters():
+                if p.requires_grad:
+                    p.data.copy_(self.backup[n])
         self.backup = {}
 
     def state_dict(self):

@@ -117,3 +117,77 @@ def test_sharded_prediction_grid_gloo(S):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert abs(res[0][1] - res[1][1]) < 1e-9
+
+
+# ------------------------------------------------------------------ epoch schedule (ragged shards)
+def test_epoch_schedule_properties():
+    """Every rank gets the same number of steps, a non-empty batch in each, all its rows exactly once, never
+    more than the batch size; equal shards keep the DataLoader shape (full batches + a ragged last one)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "st-dadk_amd"))
+    from stnf.distributed import epoch_schedule, shard_range
+    for n, world, B in [(4095, 2, 1024), (2049, 2, 1024), (4097, 2, 1024), (100_000, 8, 4096), (1_000_003, 8, 16384),
+                        (7, 2, 1024), (8193, 4, 1024), (4096 * 8, 8, 4096), (4096 * 8 + 1, 8, 4096), (6000, 2, 1)]:
+        sizes = [hi - lo for lo, hi in (shard_range(n, r, world) for r in range(world))]
+        table = epoch_schedule(sizes, B)
+        assert len(table) == -(-max(sizes) // B)
+        for r in range(world):
+            col = [row[r] for row in table]
+            assert sum(col) == sizes[r] and min(col) >= 1 and max(col) <= B, (n, world, B, col)
+        if len(set(sizes)) == 1:
+            full, rem = divmod(sizes[0], B)
+            assert [row[0] for row in table] == [B] * full + ([rem] if rem else [])
+    # the cases of ADVICE r1: (2048, 2047) and (1025, 1024) rows at B = 1024
+    assert epoch_schedule([2048, 2047], 1024) == [[1024, 1024], [1024, 1023]]
+    assert epoch_schedule([1025, 1024], 1024) == [[1024, 1023], [1, 1]]
+    # very unequal caller-made shards: the short one spreads its rows over the long one's steps
+    t = epoch_schedule([5000, 1000], 1024)
+    assert len(t) == 5 and sum(r[1] for r in t) == 1000 and min(r[1] for r in t) == 200
+    with pytest.raises(RuntimeError):
+        epoch_schedule([5000, 3], 1024)
+    assert epoch_schedule([0, 0], 16) == [] and epoch_schedule([], 16) == []
+
+
+def _sched_worker(rank, world, port, sizes, B, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "st-dadk_amd"))
+    from stnf import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        got = D.gather_shard_sizes(sizes[rank])
+        assert got == list(sizes)
+        table = D.epoch_schedule(got, B)
+        # the loop run_epoch runs: one gradient all-reduce per step and NO other collective; a rank-dependent
+        # number of steps or an extra collective on one rank would hang here (the parent's join times out)
+        w = torch.zeros(3, dtype=torch.float64)
+        seen = 0
+        for row in table:
+            mine, rows = row[rank], sum(row)
+            g = torch.full((3,), float(mine) / rows, dtype=torch.float64)      # this rank's share of a mean
+            D.allreduce_gradients(g)
+            assert torch.allclose(g, torch.ones(3, dtype=torch.float64), atol=1e-12)   # shares add up to the mean
+            w += g
+            seen += mine
+        assert seen == sizes[rank]
+        q.put((rank, len(table), float(w.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes,B", [((2048, 2047), 1024), ((1025, 1024), 1024), ((2049, 2048), 1024), ((300, 37), 64)])
+def test_epoch_schedule_keeps_collectives_matched_gloo(sizes, B):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sched_worker, args=(r, world, port, sizes, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert res[0][1] == res[1][1] and abs(res[0][2] - res[1][2]) < 1e-12

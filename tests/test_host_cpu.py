@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(handle, sym), f"{sym} declared in stdadk.h but not exported"
     assert declared == set(N.exported_symbols()), declared ^ set(N.exported_symbols())
-    assert N.lib().stdadk_abi_version() == N.ABI_VERSION == 5
+    hdr_version = int(re.search(r"#define\s+STDADK_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert N.lib().stdadk_abi_version() == N.ABI_VERSION == hdr_version
 
 
 def test_abi_struct_layout_matches_header():
