@@ -36,6 +36,12 @@ WORKLOADS = {
                name="C2 synthetic 100k obs, 3-res Wendland 32^2+64^2+72^2=10304 knots + 70 temporal"),
     "default": dict(k_spatial_centers=[25, 81, 121], k_temporal_centers=[10, 15, 45],
                     hidden_dims=[256, 256, 128], n_obs=100_000, name="reference default 227 knots"),
+    # BASELINE.json configs[2]: KAUST 2b full = 10 000 sites x 100 times = 1 M rows (the 2b files are missing
+    # blobs in the reference, SURVEY.md 8: a 2b-SHAPED synthetic field), 3-resolution basis; printed as an fp32
+    # line plus the "bf16 MLP with MFMA" variant (never as `value`)
+    "c3": dict(k_spatial_centers=[1024, 4096, 5184], k_temporal_centers=[10, 15, 45],
+               hidden_dims=[256, 256, 128], n_obs=1_000_000, sites=10_000, times=100,
+               name="C3 KAUST-2b-shaped 10000 sites x 100 times = 1M rows, 3-res Wendland 10304 knots + 70 temporal"),
     "c4": dict(k_spatial_centers=[1024, 4096, 16384, 28224], k_temporal_centers=[10, 15, 45],
                hidden_dims=[256, 256, 128], n_obs=1_000_000, name="C4 synthetic 1M obs, 4-res 49728 knots"),
 }
@@ -52,6 +58,76 @@ def synth(n, seed, device):
     y = (torch.sin(4 * np.pi * coords[:, :1]) * torch.cos(3 * np.pi * coords[:, 1:2])
          * (1 + 0.5 * torch.sin(2 * np.pi * t)) + 0.1 * torch.randn(n, 1, generator=g))
     return coords.to(device), t.to(device), y.to(device)
+
+
+def synth_sites(n_sites, n_times, seed, device):
+    """KAUST 2b shape: the same `n_sites` scattered sites observed at every one of `n_times` times, rows in the
+    reference's sample order (time-major, train_st_interp.py:413-450), t = t_idx/(T-1)."""
+    g = torch.Generator().manual_seed(seed)
+    sites = torch.rand(n_sites, 2, generator=g)
+    coords = sites.repeat(n_times, 1)
+    t = (torch.arange(n_times).float() / max(n_times - 1, 1)).repeat_interleave(n_sites).view(-1, 1)
+    y = (torch.sin(4 * np.pi * coords[:, :1]) * torch.cos(3 * np.pi * coords[:, 1:2])
+         * (1 + 0.5 * torch.sin(2 * np.pi * t)) + 0.1 * torch.randn(n_sites * n_times, 1, generator=g))
+    return coords.to(device), t.to(device), y.to(device)
+
+
+def csrc_hash():
+    """sha256 (16 hex digits) over the kernel sources the library was built from: ties a committed PMC traffic
+    figure to the exact kernels it was measured on (any source change makes it stale)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "st-dadk_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) +
+                    glob.glob(os.path.join(base, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, workload, B, dtype):
+    """(bytes per launch, source) from the committed rocprofv3 PMC summary, or (None, reason): the figure is only
+    quoted for the kernel, workload, batch, dtype AND kernel sources it was measured on."""
+    f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(f):
+        return None, "no profiles/pmc_traffic.json"
+    try:
+        tj = json.load(open(f))
+    except Exception as e:                                   # noqa: BLE001
+        return None, f"unreadable profiles/pmc_traffic.json: {e}"
+    src = tj.get("source", {})
+    want = dict(workload=workload, batch=B, dtype=dtype, csrc_sha16=csrc_hash())
+    for k, v in want.items():
+        if src.get(k) != v:
+            return None, (f"stale: profiles/pmc_traffic.json was measured at {k}={src.get(k)!r}, this run has {v!r}; "
+                          f"re-take the FETCH_SIZE / WRITE_SIZE passes (profiles/README.md)")
+    short = kernel.replace("(stdadk::", "").replace("(", "").replace(")", "").split("<")[0]
+    val = tj.get("kernels", {}).get(short)
+    if val is None:
+        return None, f"kernel {short} not in profiles/pmc_traffic.json"
+    return val, {"file": "profiles/pmc_traffic.json", "commit": src.get("commit"), "csrc_sha16": src.get("csrc_sha16"),
+                 "kernel": tj.get("kernel_names", {}).get(short, short),
+                 "how": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; 2*FETCH + WRITE (gfx950 read correction)"}
+
+
+def step_floors(B, H, Kt, Q, P_flat, nnz_per_obs):
+    """Floors of ONE whole train step (window path): bytes that cross HBM at least once and flops of the
+    mathematical products, against the chip's peaks.
+      HBM : AdamW/EMA 36 B per parameter + the gradient written once (4 B) + per row the observation (16 B),
+            what the forward keeps for the backward (xhat, act of every hidden layer: written and read once) and
+            dZ of every hidden layer (written by the backward chain, read by the weight-gradient products)
+      MFMA: forward of the layers after the first, their dA (no dA below layer 1) and dW products, the temporal
+            rows of dW0, the output layer, and layer 0 on its non-zero (observation, knot) pairs, forward and dW0."""
+    sumH = float(sum(H))
+    hbm = 40.0 * P_flat + B * (16.0 + 4.0 * 6.0 * sumH)
+    tail = sum(2.0 * H[i] * H[i - 1] for i in range(1, len(H))) + 2.0 * H[-1] * Q
+    dA = sum(2.0 * H[i] * H[i - 1] for i in range(2, len(H))) + 2.0 * H[-1] * Q + 2.0 * H[1] * H[0]
+    dW = sum(2.0 * H[i] * H[i - 1] for i in range(1, len(H))) + 2.0 * H[-1] * Q
+    l0 = 2.0 * 2.0 * (nnz_per_obs + Kt) * H[0]
+    fl = B * (tail + dA + dW + l0)
+    return {"hbm_bytes": hbm, "hbm_us": hbm / (HBM_PEAK_GBS * 1e9) * 1e6, "flops": fl,
+            "mfma_us": fl / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e6}
 
 
 def time_events(fn, iters, warm=3):
@@ -155,6 +231,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU mini-batch (reference YAML: 4096)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: the Linear layers after the first on the bf16 matrix cores (BASELINE config C3); the "
+                         "headline `value` is always the f32 line, bf16 runs are labelled as such")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (N = 1).  Off by default: on this ROCm the eager "
@@ -197,11 +276,14 @@ def main():
                         dropout=args.dropout, layernorm=True).to(dev)
     model.train()
     n_obs = wl["n_obs"]
-    coords, t, y = synth(n_obs, 2025 + rank, dev)           # each rank owns its shard of observations
+    if "sites" in wl:
+        coords, t, y = synth_sites(wl["sites"], wl["times"], 2025 + rank, dev)
+    else:
+        coords, t, y = synth(n_obs, 2025 + rank, dev)       # each rank owns its shard of observations
     batches_per_epoch = max(n_obs // B, 1)
     eng = TrainStep(model, lr=2e-2, weight_decay=5e-4, grad_clip=10.0,
                     ema_decay=1.0 - 1.0 / (10.0 * batches_per_epoch), max_batch=B,
-                    use_graph=args.graph and world == 1, force_dense=args.dense)
+                    use_graph=args.graph and world == 1, force_dense=args.dense, dtype=args.dtype)
     perm = torch.randperm(n_obs, device=dev)
 
     def batch(i):
@@ -243,12 +325,58 @@ def main():
     c, tt, yy = batch(0)
     c, tt, yy = c.contiguous(), tt.contiguous().view(-1), yy.contiguous()
     n_prof = 10
+    eng.time_allreduce = world > 1
     N.profile_enable(True)
     for _ in range(n_prof):
         eng._enqueue(None, c, tt, yy, B, B * world)
     torch.cuda.synchronize()
+    eng.time_allreduce = False
+    allreduce_ms = (sum(e0.elapsed_time(e1) for e0, e1 in eng.allreduce_events) / max(len(eng.allreduce_events), 1)
+                    if world > 1 else None)
+    eng.allreduce_events = []
     if world > 1:
         dist.barrier()
+
+    # ---- N > 1: the configuration BASELINE names for the 8-GPU run (C4: 4 resolutions, 49 728 knots, 12.85 M
+    # parameters = a 51 MB gradient) at the per-GPU batch SURVEY.md 8(e) sizes for it (>= 16 384 rows), beside the
+    # headline workload above.  Every rank takes part (the step contains the all-reduce).
+    c4_line = None
+    if world > 1 and args.workload != "c4":
+        w4 = WORKLOADS["c4"]
+        B4 = max(16384, B)
+        n4 = max(w4["n_obs"] // world, 4 * B4)
+        torch.manual_seed(0)
+        m4 = STInterpMLP(p=0, k_spatial_centers=w4["k_spatial_centers"], k_temporal_centers=w4["k_temporal_centers"],
+                         hidden_dims=w4["hidden_dims"], dropout=args.dropout, layernorm=True).to(dev)
+        m4.train()
+        c4c, c4t, c4y = synth(n4, 4025 + rank, dev)
+        e4 = TrainStep(m4, lr=2e-2, weight_decay=5e-4, grad_clip=10.0, ema_decay=0.999, max_batch=B4, dtype=args.dtype)
+        perm4 = torch.randperm(n4, device=dev)
+        nb4 = n4 // B4
+
+        def run4(k0, k):
+            for i in range(k0, k0 + k):
+                j, jn = i % nb4, (i + 1) % nb4
+                e4.step_indexed(c4c, c4t, c4y, perm4[j * B4:j * B4 + B4], global_rows=B4 * world,
+                                next_idx=None if args.no_pipeline else perm4[jn * B4:jn * B4 + B4])
+        k4 = max(10, min(args.steps, 40))
+        run4(0, 5)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        run4(5, k4)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        el4 = torch.tensor([time.perf_counter() - t4], device=dev, dtype=torch.float64)
+        dist.all_reduce(el4, op=dist.ReduceOp.MAX)
+        e4.time_allreduce = True
+        run4(5 + k4, 10)
+        torch.cuda.synchronize()
+        ar4 = sum(a0.elapsed_time(a1) for a0, a1 in e4.allreduce_events) / max(len(e4.allreduce_events), 1)
+        dist.barrier()
+        c4_line = {"workload": w4["name"], "per_gpu_batch": B4, "global_batch": B4 * world, "n_obs_per_gpu": n4,
+                   "obs_per_s": world * B4 * k4 / el4.item(), "ms_per_step": el4.item() / k4 * 1e3, "steps": k4,
+                   "gradient_bytes": 4 * e4.flat.numel(), "allreduce_ms_per_step": ar4, "scaling": "weak",
+                   "dtype": args.dtype}
+        del e4, m4, c4c, c4t, c4y
     if rank == 0:
         recs = N.profile_collect()
         N.profile_enable(False)
@@ -284,16 +412,7 @@ def main():
                 roof = {"kernel": nm, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                         "avg_launch_us": avg_us, "algorithmic_flops_per_launch": amount}
-            tr_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            # HBM bytes/launch from rocprofv3 --pmc (committed summary, measured at the default C2 / B = 4096 shape)
-            if os.path.exists(tr_file) and args.workload == "c2" and B == 4096:
-                try:
-                    tj = json.load(open(tr_file))
-                    for key, val in tj.get("kernels", {}).items():
-                        if key in nm:
-                            roof["traffic"] = val
-                except Exception:
-                    pass
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(nm, args.workload, B, args.dtype)
         # ---- the standalone materialising feature builder ("RBF-build GB/s")
         feats = torch.empty(B, (D + 31) // 32 * 32, device=dev)
         t_rbf = time_events(lambda: N.rbf_build(c, tt, None, model.spatial_basis.centers,
@@ -302,23 +421,38 @@ def main():
                                                 feats), 50)
         rbf_bytes = B * (12 + 4 * D)                         # 12 B read + 4*D written / obs
         rbf_gbs = rbf_bytes / t_rbf / 1e9
-        rbf_traffic = None                                   # HBM bytes/launch from the committed PMC summary
-        try:                                                 # (measured at the default C2 / B = 4096 shape only)
-            if args.workload == "c2" and B == 4096:
-                rbf_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(
-                    "rbf_build_kernel")
-        except Exception:
-            pass
+        rbf_traffic, rbf_traffic_src = pmc_traffic("rbf_build_kernel", args.workload, B, args.dtype)
+        del feats
+        # the same builder on a footprint well past the 256 MiB Infinity Cache (FETCH/WRITE_SIZE and a short
+        # timed loop both see cache hits below it): rows so that the written features are >= 640 MB
+        B_big = max(B, -(-640_000_000 // (4 * ((D + 31) // 32 * 32))) // 1024 * 1024 + 1024)
+        cb, tb_, _ = synth(B_big, 7, dev)
+        feats_big = torch.empty(B_big, (D + 31) // 32 * 32, device=dev)
+        t_big = time_events(lambda: N.rbf_build(cb, tb_.view(-1), None, model.spatial_basis.centers,
+                                                model.spatial_basis._bandwidths, "wendland",
+                                                model.temporal_basis.centers, model.temporal_basis.bandwidths,
+                                                feats_big), 20)
+        big_bytes = B_big * (12 + 4 * D)
+        rbf_big = {"bound": "hbm", "achieved": big_bytes / t_big / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": big_bytes / t_big / 1e9 / HBM_PEAK_GBS, "rows": B_big, "bytes_per_launch": big_bytes,
+                   "avg_launch_us": t_big * 1e6, "traffic": None,
+                   "note": "footprint past the 256 MiB Infinity Cache: every byte of the write stream reaches HBM"}
+        del feats_big, cb, tb_
+        Q = model.output_dim
+        floors = step_floors(B, H, Kt, Q, P_flat, nnz / B)
+        ms_step = el / args.steps * 1e3
         out = {
             "metric": "train-step samples/sec (obs points/sec)", "value": args.gpus * B * args.steps / el,
             "unit": "obs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["name"], "per_gpu_batch": B, "global_batch": B * args.gpus,
                        "n_obs_per_gpu": n_obs, "dropout": args.dropout, "layernorm": True,
                        "optimizer": "AdamW lr 2e-2 wd 5e-4 clip 10 + EMA",
-                       "path": ("index-window layer 1 (compact support) + fp32 MFMA MLP" if eng.uses_window
-                                else "materialised features + dense fp32 MFMA MLP"),
+                       "path": (("index-window layer 1 (compact support) + " if eng.uses_window
+                                 else "materialised features + dense ") +
+                                ("fp32 MFMA MLP" if args.dtype == "f32" else
+                                 "bf16-operand MFMA MLP after the first layer (fp32 accumulate / LayerNorm / master weights)")),
                        "hipgraph": bool(eng.use_graph),
                        "batch_preparation": "pipelined on a side stream" if (eng.uses_window and not args.no_pipeline
                                                                               and not eng.use_graph) else "in the step",
@@ -326,12 +460,28 @@ def main():
             "roofline": roof,
             "rbf_build": {"bound": "hbm", "achieved": rbf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": rbf_gbs / HBM_PEAK_GBS, "bytes_per_obs": 12 + 4 * D, "avg_launch_us": t_rbf * 1e6,
-                          "traffic": rbf_traffic, "note": "one launch of stdadk_rbf_build_f32 over all column tiles"},
+                          "traffic": rbf_traffic, "traffic_source": rbf_traffic_src,
+                          "note": "one launch of stdadk_rbf_build_f32 over all column tiles; at this batch the "
+                                  "features fit the 256 MiB Infinity Cache -- rbf_build_past_l3 is the HBM figure"},
+            "rbf_build_past_l3": rbf_big,
+            "step_floor_us": {"hbm": round(floors["hbm_us"], 2), "mfma_f32": round(floors["mfma_us"], 2),
+                              "hbm_bytes": floors["hbm_bytes"], "flops": floors["flops"],
+                              "step_us": round(ms_step * 1e3, 2),
+                              "frac_of_step": round(max(floors["hbm_us"], floors["mfma_us"]) / (ms_step * 1e3), 4),
+                              "note": "floors of the WHOLE step (bench.step_floors): bytes that must cross HBM at "
+                                      "8 TB/s, flops of the mathematical products at the fp32 MFMA peak"},
             "kernels_us_per_step": kernels_us,
             "kernel_time_us_per_step": round(sum(r[3] for r in per_step), 1),
             "nonzero_obs_knot_pairs_per_obs": nnz / B,
             "final_mean_loss": loss,
         }
+        if world > 1:
+            # the one collective of the path, timed with events around it on the step's stream (rank 0's view;
+            # it includes waiting for the slowest rank to arrive)
+            out["allreduce"] = {"ms_per_step": allreduce_ms, "gradient_bytes": 4 * P_flat,
+                                "algorithm_bandwidth_GBs": 4 * P_flat / (allreduce_ms * 1e-3) / 1e9 if allreduce_ms else None}
+            if c4_line is not None:
+                out["c4_weak_scaling_line"] = c4_line
         if args.gpus == 1 and not args.no_sweep:
             def timed(b2, k2, model_kw=None, eng_kw=None, graph=None):
                 """obs/s of the same fused step for another batch size / objective / knot mode."""
@@ -364,6 +514,13 @@ def main():
             out["batch_sweep"] = {str(b2): timed(b2, 40) for b2 in (16384, 65536) if b2 != B and b2 <= n_obs}
             # the same step replayed from a hipGraph / launched eagerly (whichever `value` did not use)
             out["other_launch_mode"] = dict(timed(B, 100, graph=not args.graph), hipgraph=not args.graph)
+            # BASELINE config C3's "bf16 MLP with MFMA": the same step with bf16 operands in the Linear layers after
+            # the first (fp32 accumulation / LayerNorm / loss / master weights); labelled, never `value`
+            if args.dtype == "f32":
+                out["bf16_mlp"] = {"dtype": "bf16 operands, f32 accumulate", "note": "TrainStep(dtype='bf16'); parity: "
+                                   "tests/test_gpu_bf16.py (emulation of the operand rounding + float64 goldens)",
+                                   **{str(b2): timed(b2, 40 if b2 > B else 100, eng_kw=dict(dtype="bf16"))
+                                      for b2 in (B, 16384, 65536) if b2 <= n_obs}}
             # the "next" rows of SURVEY.md §8(f) on the same workload and batch: multi-quantile objectives
             # (N3) and learnable knots (N2, materialising path); reported beside, never as, `value`
             taus = [0.05, 0.25, 0.5, 0.75, 0.95]
@@ -422,6 +579,36 @@ def main():
             dt = (time.perf_counter() - t1) / 5
             out["variants"]["inference_site_x_time_grid"] = {"obs_per_s": S_g * T_g / dt, "ms_per_call": dt * 1e3,
                                                              "sites": S_g, "times": T_g, "path": "window"}
+            # BASELINE config C5: 10 M-point dense prediction grid (100 000 sites x 100 times), forward only, one GPU:
+            # the site x time decomposition, and row by row through the chunked Predictor, eager and replayed from
+            # a hipGraph per chunk
+            S5, T5 = 100_000, 100
+            g5 = torch.Generator().manual_seed(5)
+            c5 = torch.rand(S5, 2, generator=g5).to(dev)
+            tv5 = (torch.arange(T5, device=dev, dtype=torch.float32) / (T5 - 1))
+            c5_res = {"points": S5 * T5, "sites": S5, "times": T5}
+            pr.predict_grid(c5, tv5)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                yg5 = pr.predict_grid(c5, tv5)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 3
+            c5_res["site_x_time_grid"] = {"points_per_s": S5 * T5 / dt, "ms_per_call": dt * 1e3}
+            cc5, tt5 = c5.repeat(T5, 1), tv5.repeat_interleave(S5)
+            for label, prd in (("rows_eager", pr), ("rows_hipgraph", Predictor(model, use_graph=True))):
+                yr5 = prd.predict(cc5, tt5)
+                yr5 = prd.predict(cc5, tt5)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    yr5 = prd.predict(cc5, tt5)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 2
+                c5_res[label] = {"points_per_s": S5 * T5 / dt, "ms_per_call": dt * 1e3,
+                                 "max_abs_diff_vs_grid": float((yr5.view(T5, S5, -1) - yg5).abs().max())}
+            del cc5, tt5, yr5, yg5
+            out["variants"]["inference_c5_10M"] = c5_res
             model.train()
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, B, args.dropout)

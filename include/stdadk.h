@@ -78,12 +78,18 @@ typedef struct stdadk_mlp_desc {
 
 /* Device pointers of the parameters / their gradients; layer l = 0..L-1 are the hidden Linear
  * (+LayerNorm) layers, layer L is the output Linear.  W[l] is (out,in) row-major contiguous as
- * nn.Linear stores it; ln_g/ln_b are NULL when layernorm == 0. */
+ * nn.Linear stores it; ln_g/ln_b are NULL when layernorm == 0.
+ * W_bf16 / WT_bf16 (parameters only, read with STDADK_FLAG_BF16; NULL otherwise): bfloat16 copies of the
+ * hidden layers l >= 1 -- W_bf16[l] is W[l] rounded to nearest-even, (out,in) row-major; WT_bf16[l] its
+ * transpose (in,out) row-major (the K-contiguous operand of dA = dZ W).  stdadk_bf16_shadow_refresh makes
+ * them, the optimiser entry points keep them current (stdadk_bf16_shadow). */
 typedef struct stdadk_mlp_tensors {
   float *W[STDADK_MAX_HIDDEN + 1];
   float *b[STDADK_MAX_HIDDEN + 1];
   float *ln_g[STDADK_MAX_HIDDEN];
   float *ln_b[STDADK_MAX_HIDDEN];
+  uint16_t *W_bf16[STDADK_MAX_HIDDEN + 1];
+  uint16_t *WT_bf16[STDADK_MAX_HIDDEN + 1];
 } stdadk_mlp_tensors;
 
 /* Bytes of workspace stdadk_mlp_forward_f32/backward_f32 need for B rows (saved activations +
@@ -179,13 +185,32 @@ int stdadk_delta_head_backward_f32(const float *delta, const float *dWo, const f
 int stdadk_sumsq_f32(const float *g, int64_t n, float *parts, int32_t *step_inc,
                      stdadk_stream_t stream);
 
+/* BASELINE config C3 ("bf16 MLP with MFMA"): fp32 MASTER weights, bf16 OPERAND copies.  A shadow table names
+ * up to STDADK_MAX_HIDDEN regions of a flat fp32 parameter buffer, each a (rows, cols) row-major matrix at
+ * element offset `off` (off and cols multiples of 4), with the bf16 copy `dst` [rows][cols] and its transpose
+ * `dst_t` [cols][rows] (either may be NULL).  stdadk_bf16_shadow_refresh rewrites every region from p (after
+ * load_state_dict, an EMA swap, ...); the optimiser entry points below take the table as an optional last
+ * argument and rewrite the copies from the values they have just stepped, in the same pass (offsets relative
+ * to the `p` of that call).  Rounding: round-to-nearest-even (v_cvt_pk_bf16_f32). */
+typedef struct stdadk_bf16_region {
+  int64_t off;          /* first element of the matrix in the flat buffer                     */
+  int32_t rows, cols;
+  uint16_t *dst;        /* [rows][cols] bf16 or NULL                                          */
+  uint16_t *dst_t;      /* [cols][rows] bf16 or NULL                                          */
+} stdadk_bf16_region;
+typedef struct stdadk_bf16_shadow {
+  int32_t n;                                     /* regions in use                            */
+  stdadk_bf16_region r[STDADK_MAX_HIDDEN];
+} stdadk_bf16_shadow;
+int stdadk_bf16_shadow_refresh(const float *p, const stdadk_bf16_shadow *shadow, stdadk_stream_t stream);
+
 int stdadk_step_advance(int32_t *step_dev, stdadk_stream_t stream);
 
 int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
                          float lr, const float *lr_dev, float beta1, float beta2, float eps,
                          float weight_decay, int32_t step, const int32_t *step_dev, float max_norm,
                          const float *sumsq_parts, int32_t n_parts, float grad_mul, float ema_decay,
-                         stdadk_stream_t stream);
+                         const stdadk_bf16_shadow *shadow, stdadk_stream_t stream);
 
 /* A9 with two parameter groups in one launch each (learnable knots: the MLP parameters and the knot
  * tensors are clipped on their own norms and stepped with their own learning rates,
@@ -201,6 +226,7 @@ typedef struct stdadk_adam_group {
   float max_norm;             /* <= 0: no clipping                                               */
   const float *sumsq_parts;   /* partial sums of squares of g (stdadk_sumsq*_f32)                */
   int32_t n_parts;
+  const stdadk_bf16_shadow *shadow;   /* bf16 operand copies to keep current (NULL = none)       */
 } stdadk_adam_group;
 int stdadk_sumsq2_f32(const float *g0, int64_t n0, float *parts0, const float *g1, int64_t n1,
                       float *parts1, int32_t *step_inc, stdadk_stream_t stream);
@@ -242,6 +268,14 @@ typedef struct stdadk_basis_desc {
 #define STDADK_FLAG_PREBINNED 16 /* window path: the batch was already binned into this workspace by
                               * stdadk_bin_batch_f32 (e.g. on another stream while the previous step
                               * ran); the step entry points skip the binning and ignore coords/t/X/y */
+#define STDADK_FLAG_BF16 32 /* BASELINE config C3: the Linear layers AFTER the first run on the bf16 matrix
+                              * cores (v_mfma_f32_16x16x32_bf16 in the fused tail kernels, v_mfma_f32_32x32x16_bf16
+                              * in the grouped weight-gradient products): operands rounded to bf16 at the
+                              * operand boundary (activations as they enter LDS, weights from
+                              * params->W_bf16 / WT_bf16), fp32 accumulation, fp32 LayerNorm statistics,
+                              * fp32 loss, fp32 master weights / gradients / optimiser state.  phi and psi are
+                              * evaluated in fp32 and layer 0 stays fp32 on both paths.  Needs the fused tail
+                              * kernels (hidden widths multiples of 16 up to 256); STDADK_E_ARG otherwise */
 #define STDADK_FLAG_WINDOW 8 /* take the window path whenever it is supported, even for small knot
                               * tables (default: tables under 1024 knots run the materialising
                               * path, which is faster there: a coarse level's few knots each own a
@@ -399,6 +433,7 @@ typedef struct stdadk_optim_desc {
   float max_norm;               /* clip_grad_norm_ threshold; <= 0: no clipping                    */
   float *sumsq_parts;           /* [STDADK_GRADSQ_PARTS] device scratch                            */
   float ema_decay;
+  const stdadk_bf16_shadow *shadow;   /* bf16 operand copies to keep current (NULL = none)           */
 } stdadk_optim_desc;
 int stdadk_train_step_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
                           const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,

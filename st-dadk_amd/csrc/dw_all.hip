@@ -14,7 +14,7 @@ static_assert(GT == BW_T, "the GEMM tiles and the knot groups must share the wor
 // NK (fixed knots only): 2 neighbouring knots per wave, see l1_window_bwd_multi_body; 1: one knot per wave
 template <int CPL, int BASIS, bool KNOTS, int NK>
 __global__ __launch_bounds__(GT) void dw_all_kernel(GemmGroup grp, int n_gemm_blocks, L1BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[TileGeom<64, true>::SIZE * 2];
+  __shared__ __attribute__((aligned(16))) float lds[GROUP_LDS_FLOATS];
   // GEMM tiles take the low block ids (dispatched first): measured 33.5 us vs 42.5 us the other way round
   if ((int)blockIdx.x < n_gemm_blocks) { gemm_tn_grouped_block(grp, (int)blockIdx.x, lds); return; }
   // XCD-striped knot groups start at a multiple of 8, so that (group block & 7) is the XCD of the workgroup

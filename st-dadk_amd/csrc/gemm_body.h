@@ -207,6 +207,108 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 operands for the TN products of a step (STDADK_FLAG_BF16): C[64 x 64] = A^T B over a K slice, both operands
+// stored K-major in fp32 ([k][rows]).  The tiles are rounded to bf16 as they are stored to LDS (the operand
+// boundary), [64 k][64 rows] images with a 96-element row stride, and the K-contiguous fragments the MFMA wants
+// come from the transposing LDS read: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a
+// 4 (k) x 16 (rows) block.  v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8(l>>5) + j], B[k][col l&31].
+// Stride 96 (192 B = 48 banks): the four k-rows of the two blocks a 32-lane half reads fall on eight disjoint
+// 8-bank runs -- conflict-free.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned short hu16;
+typedef short hs16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BKH = 64;            // k per stage
+constexpr int HSTRIDE = 96;        // bf16 elements per k-row of an LDS image
+constexpr int GROUP_LDS_FLOATS = (2 * BKH * HSTRIDE * 2) / 4 > TileGeom<64, true>::SIZE * 2 ? (2 * BKH * HSTRIDE * 2) / 4
+                                                                                             : TileGeom<64, true>::SIZE * 2;
+
+__device__ __forceinline__ uint32_t h_pack(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// rows r0.. of k-rows k0.. of a K-major fp32 operand into registers: 4 float4 per thread, unconditional clamped
+// loads masked in registers (see load_tile)
+__device__ __forceinline__ void h_load(const float *__restrict__ P, int64_t ld, int r0, int nrows, int k0, int kend,
+                                       float4 *reg) {
+  const int tid = threadIdx.x;
+  const int r = r0 + (tid & 15) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kk = (tid >> 4) + 16 * i;
+    const bool kok = (k0 + kk) < kend;
+    const float4 v = *reinterpret_cast<const float4 *>(P + (int64_t)(kok ? k0 + kk : k0) * ld + (r < nrows ? r : r0));
+    reg[i] = make_float4((kok && r + 0 < nrows) ? v.x : 0.f, (kok && r + 1 < nrows) ? v.y : 0.f,
+                         (kok && r + 2 < nrows) ? v.z : 0.f, (kok && r + 3 < nrows) ? v.w : 0.f);
+  }
+}
+__device__ __forceinline__ void h_store(hu16 *lds, const float4 *reg) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kk = (tid >> 4) + 16 * i;
+    *reinterpret_cast<uint2 *>(lds + kk * HSTRIDE + (tid & 15) * 4) = make_uint2(h_pack(reg[i].x, reg[i].y), h_pack(reg[i].z, reg[i].w));
+  }
+}
+// fragment of the 16-deep k-step s for the 32 rows starting at `row`: two transposing reads (k = 8h + 0..3, + 4..7)
+__device__ __forceinline__ hbf16x8 h_frag(const hu16 *lds, int row, int s, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const hu16 *p = lds + (16 * s + 8 * (g >> 1) + (i >> 2)) * HSTRIDE + row + 16 * (g & 1) + 4 * (i & 3);
+  typedef __attribute__((address_space(3))) hs16x4 lds_s16x4;
+  const hs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p);
+  const hs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 4 * HSTRIDE));
+  typedef short hs16x8 __attribute__((ext_vector_type(8)));
+  const hs16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(hbf16x8, v);
+}
+
+__device__ __forceinline__ void gemm_tn_tile_body_h(const GemmArgs &g, int bx, int by, int bz, float *lds_f) {
+  hu16 *As = reinterpret_cast<hu16 *>(lds_f), *Bs = As + BKH * HSTRIDE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = by * 64, n0 = bx * 64;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  int kbeg = 0, kend = g.K;
+  if (g.splits > 1) {
+    kbeg = bz * g.kps;
+    kend = min(g.K, kbeg + g.kps);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 ra[4], rb[4];
+  if (kbeg < kend) {
+    h_load(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+    h_load(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BKH) {
+    h_store(As, ra);
+    h_store(Bs, rb);
+    __syncthreads();
+    if (k0 + BKH < kend) {
+      h_load(g.A, g.lda, m0, g.M, k0 + BKH, kend, ra);
+      h_load(g.B, g.ldb, n0, g.N, k0 + BKH, kend, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < BKH / 16; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h_frag(As, wm, s, lane), h_frag(Bs, wn, s, lane), acc, 0, 0, 0);
+    __syncthreads();
+  }
+  // epilogue as the fp32 tiles: always a slab (grouped jobs)
+  float *Cbase = g.slab + (int64_t)bz * g.slab_stride;
+  const int h = lane >> 5, cl = lane & 31;
+  const int col = n0 + wn + cl;
+  if (col < g.N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < g.M) Cbase[(int64_t)row * g.N + col] = acc[r];
+    }
+  }
+}
+
 // one workgroup of a grouped TN launch: block -> (job, tile, split) through the prefix table
 __device__ __forceinline__ void gemm_tn_grouped_block(const GemmGroup &grp, int block, float *lds) {
   int j = 0;
@@ -216,7 +318,8 @@ __device__ __forceinline__ void gemm_tn_grouped_block(const GemmGroup &grp, int 
   const int tn = (g.N + 63) >> 6, tm = (g.M + 63) >> 6;
   const int bz = b / (tn * tm);
   b -= bz * tn * tm;
-  gemm_tile_body<64, 64, true, true, 4, 4>(g, b % tn, b / tn, bz, lds);
+  if (g.bf16) gemm_tn_tile_body_h(g, b % tn, b / tn, bz, lds);      // workgroup-uniform
+  else gemm_tile_body<64, 64, true, true, 4, 4>(g, b % tn, b / tn, bz, lds);
 }
 
 }  // namespace stdadk

@@ -25,6 +25,8 @@ struct GemmArgs {
   float *slab;        // splits * slab_stride floats when splits > 1
   int64_t slab_stride;
   int always_slab = 0;  // write the (single) partial to the slab even when splits == 1
+  int bf16 = 0;         // grouped TN jobs only (STDADK_FLAG_BF16): operands rounded to bf16 as they enter LDS,
+                        // v_mfma_f32_32x32x16_bf16, fp32 accumulate
 };
 
 // a table of TN products for one launch (gemm_tn_grouped_kernel) and of partial-sum reductions

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(GT) void gemm_f32_kernel(GemmArgs g) {
 // Several independent C_j = A_j^T B_j products (reduction over the batch) in ONE launch: block ->
 // (job, tile, split) through a prefix table; every job writes split-K slabs.
 __global__ __launch_bounds__(GT) void gemm_tn_grouped_kernel(GemmGroup grp) {
-  __shared__ __attribute__((aligned(16))) float lds[TileGeom<64, true>::SIZE * 2];
+  __shared__ __attribute__((aligned(16))) float lds[GROUP_LDS_FLOATS];
   gemm_tn_grouped_block(grp, (int)blockIdx.x, lds);
 }
 

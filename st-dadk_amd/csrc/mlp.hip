@@ -502,6 +502,8 @@ struct Ctx {
   // materialising path, small D: layer 0 starts inside the tail launch from the raw observations (TailDense0)
   bool d0 = false;
   const float *d0_coords = nullptr, *d0_t = nullptr, *d0_X = nullptr, *d0_bw = nullptr;
+  bool bf16 = false;            // STDADK_FLAG_BF16: bf16 operands in the fused tail kernels (P->W_bf16 / WT_bf16)
+  bool cap32 = false;           // this batch's tail launches use <= 32-row tiles (bf16 + dense layer 0 in the launch)
   bool save = true;             // false in eval mode: the forward keeps nothing for a backward (xhat, rstd, act, psi)
   bool log_bw = false;          // basis->s_bw holds log-bandwidths (learnable knots)
   const int64_t *idx = nullptr; // window path: the batch is rows idx[b] of the resident observation arrays
@@ -554,6 +556,8 @@ static TailLayer tail_layer(const Ctx &c, int l) {
   TailLayer t;
   const stdadk_mlp_desc *d = c.d;
   t.W = c.P->W[l]; t.b = c.P->b[l];
+  t.Wbf = c.bf16 ? c.P->W_bf16[l] : nullptr;
+  t.WTbf = c.bf16 ? c.P->WT_bf16[l] : nullptr;
   t.g = d->layernorm ? c.P->ln_g[l] : nullptr;
   t.be = d->layernorm ? c.P->ln_b[l] : nullptr;
   t.h = d->hidden[l];
@@ -650,6 +654,8 @@ static int run_forward(Ctx &c, int l0, const float *in, int64_t ld_in, int K, fl
     a.loss = c.loss;
     if (a.loss.y_cols == 0) a.loss.y_cols = Q;
     a.layernorm = d->layernorm; a.eps = d->ln_eps; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
+    a.bf16 = c.bf16 ? 1 : 0;
+    c.cap32 = c.bf16 && a.d0.on != 0;
     c.mse_done = c.mse_y != nullptr;
     { const char *e = getenv("STDADK_TAIL_STAMPS"); a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     if (c.fuse_tail && c.mse_done) { c.pend = a; c.pend_valid = true; return 0; }
@@ -690,7 +696,10 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
 
   if (tail_enabled() && !c.masks && L >= 1 && tail_supported(d, 1)) {
     // one kernel for the whole activation-gradient path, then reductions and the dW GEMMs
-    const int64_t nb16 = ceil_div(B, tail_rows(B));      // workgroups of the fused backward = partial rows
+    // (a split backward call cannot know whether its forward ran the dense layer 0 inside the launch: every
+    //  bf16 backward on the materialising path with D <= TAIL_D0_MAX takes the 32-row cap the forward took)
+    const bool cap32 = c.pend_valid ? c.cap32 : (c.bf16 && layer0_dense && c.w0t && d->in_dim <= TAIL_D0_MAX);
+    const int64_t nb16 = ceil_div(B, tail_rows(B, cap32));      // workgroups of the fused backward = partial rows
     const int hL = d->hidden[L - 1];
     TailBwdArgs a;
     a.n_layers = L;
@@ -705,6 +714,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     a.B = (int)B; a.Wo = P->W[L]; a.Q = Q; a.dY = dY;
     a.act_last = ws + pl.act[L - 1]; a.part_head = part;
     a.layernorm = d->layernorm; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
+    a.bf16 = c.bf16 ? 1 : 0;
     { const char *e = getenv("STDADK_TAIL_BWD_STAMPS"); a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     if (c.pend_valid) {
       c.pend_valid = false;
@@ -715,7 +725,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
         rc = tail_forward_backward(c.pend, a, st);
       }
     } else {
-      rc = tail_backward(a, st);
+      rc = tail_backward(a, st, cap32);
     }
     if (rc) return rc;
     c.dz0 = ws + pl.dZl[0];
@@ -734,11 +744,14 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
       return true;
     };
     // C[M][N] (contiguous) = A^T Bm, both operands stored [B rows][.]; falls back to a stand-alone GEMM
-    auto add_tn = [&](const float *A, int64_t lda, const float *Bm, int64_t ldb, int M, int N, float *C) -> int {
+    // (`bf`: a layer after the first under STDADK_FLAG_BF16 -- operands rounded to bf16 at the LDS boundary)
+    auto add_tn = [&](const float *A, int64_t lda, const float *Bm, int64_t ldb, int M, int N, float *C,
+                      bool bf = false) -> int {
       if (gg.n < GEMM_GROUP_MAX && rg.n < REDUCE_GROUP_MAX && gemm_tn_groupable(A, lda, Bm, ldb)) {
         GemmArgs &g = gg.job[gg.n++];
         g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = N; g.bias = nullptr;
         g.M = M; g.N = N; g.K = (int)B;
+        g.bf16 = bf ? 1 : 0;
         g.splits = gemm_pick_splits(M, N, (int)B, &g.kps, false);
         g.slab = slab + slab_off; g.slab_stride = (int64_t)M * N;
         slab_off += (size_t)g.splits * M * N;
@@ -760,7 +773,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
       add_reduce(pp + 2 * h, G->b[l], h, (int)nb16, (int64_t)3 * h);
       if (l == 0) break;
       // dW_l[h][kin] = dZ_l^T act_{l-1}
-      rc = add_tn(ws + pl.dZl[l], h, ws + pl.act[l - 1], d->hidden[l - 1], h, d->hidden[l - 1], G->W[l]);
+      rc = add_tn(ws + pl.dZl[l], h, ws + pl.act[l - 1], d->hidden[l - 1], h, d->hidden[l - 1], G->W[l], c.bf16);
       if (rc) return rc;
     }
     for (int e = 0; e < c.n_extra; ++e) {
@@ -1078,6 +1091,10 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
   *window = want_window(b, d, flags);
   make_plan(d, B, &c.pl, *window ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt, learn_ks(b, flags));
   c.log_bw = (flags & STDADK_FLAG_LOG_BW) != 0;
+  c.bf16 = (flags & STDADK_FLAG_BF16) != 0;
+  STDADK_REQUIRE(!c.bf16 || (tail_enabled() && d->n_hidden >= 1 && tail_supported(d, 1)), STDADK_E_ARG,
+                 "step: STDADK_FLAG_BF16 needs the fused tail kernels (hidden widths multiples of 16 up to %d, out_dim <= %d)",
+                 TAIL_MAX_W, TAIL_MAXQ);
   STDADK_REQUIRE(workspace_bytes >= c.pl.total_floats * sizeof(float), STDADK_E_WORKSPACE,
                  "step: workspace %zu < %zu bytes", workspace_bytes, c.pl.total_floats * sizeof(float));
   c.d = d; c.ws = (float *)workspace; c.B = B;
@@ -1314,6 +1331,7 @@ extern "C" int stdadk_forward_parts_f32(const stdadk_mlp_desc *d, const stdadk_m
   auto layer = [&](int l) {
     TailLayer tl;
     tl.W = P->W[l]; tl.b = P->b[l];
+    tl.Wbf = P->W_bf16[l]; tl.WTbf = P->WT_bf16[l];
     tl.g = d->layernorm ? P->ln_g[l] : nullptr; tl.be = d->layernorm ? P->ln_b[l] : nullptr;
     tl.h = d->hidden[l]; tl.hp = l > 0 ? d->hidden[l - 1] : d->in_dim;
     tl.xhat = tl.rstd = tl.act = nullptr;
@@ -1338,6 +1356,9 @@ extern "C" int stdadk_forward_parts_f32(const stdadk_mlp_desc *d, const stdadk_m
   a.loss = LossDev{STDADK_LOSS_MSE, Q, {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f}, 0.f, 1};
   a.layernorm = d->layernorm; a.eps = d->ln_eps; a.drop_p = 0.f; a.seed = 0; a.step_dev = nullptr;
   a.stamps = nullptr;
+  // bf16 operands whenever the caller supplies the copies of every layer after the first
+  a.bf16 = L > 1 ? 1 : 0;
+  for (int l = 1; l < L; ++l) if (!P->W_bf16[l]) a.bf16 = 0;
   return tail_forward(a, (hipStream_t)stream);
 }
 
@@ -1514,7 +1535,7 @@ extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_ml
   }
   return stdadk_adamw_ema_f32(o->p, o->g, o->m, o->v, o->ema, o->n, o->lr, o->lr_dev, o->beta1, o->beta2, o->eps,
                               o->weight_decay, 1, o->step_dev, o->max_norm, clip ? o->sumsq_parts : nullptr, n_parts,
-                              1.0f, o->ema_decay, stream);
+                              1.0f, o->ema_decay, o->shadow, stream);
 }
 
 extern "C" int stdadk_bin_batch_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,

@@ -47,6 +47,13 @@ __global__ __launch_bounds__(256) void sumsq2_kernel(const float *__restrict__ g
   else sumsq_block(g1, n1, parts1, nullptr, (int)blockIdx.x - SUMSQ_PARTS);
 }
 
+// bf16 operand copies of some matrices of the flat buffer (stdadk_bf16_shadow), by value in the kernel arguments
+struct ShadowArgs {
+  int n;
+  int64_t lo, hi;                       // union of the regions' element ranges: one compare rejects the rest
+  stdadk_bf16_region r[STDADK_MAX_HIDDEN];
+};
+
 struct AdamArgs {
   float *p; const float *g; float *m; float *v; float *ema;
   int64_t n;
@@ -54,9 +61,68 @@ struct AdamArgs {
   float beta1, beta2, eps, wd;
   int step; const int *step_dev;
   float max_norm; const float *sumsq; int n_parts; float grad_mul; float ema_decay;
+  ShadowArgs sh;
 };
 
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float *ema, float gm,
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 v = {(__bf16)a, (__bf16)b};          // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// the four values p of flat elements e .. e+3 into whichever region holds them (regions start and end on
+// multiples of 4 elements and have cols % 4 == 0, so the four share a region and a row)
+__device__ __forceinline__ void shadow_store(const ShadowArgs &sh, int64_t e, float4 p) {
+#pragma unroll 1
+  for (int i = 0; i < sh.n; ++i) {
+    const stdadk_bf16_region &r = sh.r[i];
+    const int64_t idx = e - r.off;
+    if (idx < 0 || idx >= (int64_t)r.rows * r.cols) continue;
+    const uint32_t lo = pack_bf16(p.x, p.y), hi = pack_bf16(p.z, p.w);
+    if (r.dst) *reinterpret_cast<uint2 *>(r.dst + idx) = make_uint2(lo, hi);
+    if (r.dst_t) {
+      const int row = (int)(idx / r.cols), col = (int)(idx - (int64_t)row * r.cols);
+      uint16_t *t = r.dst_t + (size_t)col * r.rows + row;
+      t[0] = (uint16_t)(lo & 0xffffu); t[r.rows] = (uint16_t)(lo >> 16);
+      t[2 * (size_t)r.rows] = (uint16_t)(hi & 0xffffu); t[3 * (size_t)r.rows] = (uint16_t)(hi >> 16);
+    }
+    return;
+  }
+}
+
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const float *__restrict__ p, ShadowArgs sh) {
+  const int64_t n4 = (sh.hi - sh.lo) / 4;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = sh.lo + 4 * j;
+    shadow_store(sh, e, *reinterpret_cast<const float4 *>(p + e));
+  }
+}
+
+static int fill_shadow(ShadowArgs &o, const stdadk_bf16_shadow *sh, const float *p, int64_t n) {
+  o.n = 0; o.lo = 0; o.hi = 0;
+  if (!sh || sh->n == 0) return 0;
+  STDADK_REQUIRE(sh->n > 0 && sh->n <= STDADK_MAX_HIDDEN, STDADK_E_ARG, "bf16 shadow: %d regions (1..%d)", sh->n,
+                 STDADK_MAX_HIDDEN);
+  STDADK_REQUIRE(aligned16(p), STDADK_E_ALIGN, "bf16 shadow: the parameter buffer must be 16-byte aligned");
+  for (int i = 0; i < sh->n; ++i) {
+    const stdadk_bf16_region &r = sh->r[i];
+    const int64_t cnt = (int64_t)r.rows * r.cols;
+    STDADK_REQUIRE(r.rows > 0 && r.cols > 0 && (r.cols & 3) == 0 && (r.off & 3) == 0 && r.off >= 0 &&
+                       (n < 0 || r.off + cnt <= n),
+                   STDADK_E_SHAPE, "bf16 shadow: region %d (off %lld, %d x %d) outside the buffer or not 4-aligned", i,
+                   (long long)r.off, r.rows, r.cols);
+    STDADK_REQUIRE((!r.dst || (reinterpret_cast<uintptr_t>(r.dst) & 7) == 0) && (r.dst || r.dst_t), STDADK_E_ALIGN,
+                   "bf16 shadow: region %d copies NULL or not 8-byte aligned", i);
+    o.r[i] = r;
+    if (i == 0 || r.off < o.lo) o.lo = r.off;
+    if (i == 0 || r.off + cnt > o.hi) o.hi = r.off + cnt;
+  }
+  o.n = sh->n;
+  return 0;
+}
+
+// (the EMA value travels by reference + flag: a pointer to a local would put it in scratch memory)
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float &ema, bool has_ema, float gm,
                                          float decay_mul, float b1, float b2, float step_size,
                                          float inv_sqrt_bc2, float eps, float ema_decay) {
   g *= gm;
@@ -65,7 +131,7 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
   v = fmaf(b2, v, (1.f - b2) * g * g);
   float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
   p -= step_size * (m / denom);
-  if (ema) *ema = fmaf(ema_decay, *ema, (1.f - ema_decay) * p);
+  if (has_ema) ema = fmaf(ema_decay, ema, (1.f - ema_decay) * p);
 }
 
 __device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int block, const int nblocks) {
@@ -126,22 +192,29 @@ __device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int blo
       }
       float4 m = make_float4(mt.x, mt.y, mt.z, mt.w), v = make_float4(vt.x, vt.y, vt.z, vt.w);
       float4 e = make_float4(et.x, et.y, et.z, et.w);
-      float *ep = a.ema ? &e.x : nullptr;
-      adam_one(p.x, g.x, m.x, v.x, ep, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
-      adam_one(p.y, g.y, m.y, v.y, ep ? ep + 1 : nullptr, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
-      adam_one(p.z, g.z, m.z, v.z, ep ? ep + 2 : nullptr, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
-      adam_one(p.w, g.w, m.w, v.w, ep ? ep + 3 : nullptr, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
+      const bool he = a.ema != nullptr;
+      adam_one(p.x, g.x, m.x, v.x, e.x, he, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
+      adam_one(p.y, g.y, m.y, v.y, e.y, he, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
+      adam_one(p.z, g.z, m.z, v.z, e.z, he, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
+      adam_one(p.w, g.w, m.w, v.w, e.w, he, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
       reinterpret_cast<float4 *>(a.p)[j] = p;
       __builtin_nontemporal_store((nt4){m.x, m.y, m.z, m.w}, reinterpret_cast<nt4 *>(a.m) + j);
       __builtin_nontemporal_store((nt4){v.x, v.y, v.z, v.w}, reinterpret_cast<nt4 *>(a.v) + j);
       if (a.ema) __builtin_nontemporal_store((nt4){e.x, e.y, e.z, e.w}, reinterpret_cast<nt4 *>(a.ema) + j);
     }
     done = n4 * 4;
+    // bf16 operand copies (STDADK_FLAG_BF16): a pass of its own over this thread's float4 groups inside the
+    // regions' range, re-reading what the thread itself has just stored -- inside the loop above the table walk
+    // cost the whole stream 40 VGPRs (5 instead of 8 waves per SIMD)
+    if (a.sh.n > 0) {
+      for (int64_t j = i0; j < n4; j += stride)
+        if (4 * j >= a.sh.lo && 4 * j < a.sh.hi) shadow_store(a.sh, 4 * j, reinterpret_cast<const float4 *>(a.p)[j]);
+    }
   }
   for (int64_t j = done + i0; j < a.n; j += stride) {
     float p = a.p[j], m = a.m[j], v = a.v[j];
     float e = a.ema ? a.ema[j] : 0.f;
-    adam_one(p, a.g[j], m, v, a.ema ? &e : nullptr, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
+    adam_one(p, a.g[j], m, v, e, a.ema != nullptr, gm, decay_mul, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps, a.ema_decay);
     a.p[j] = p; a.m[j] = m; a.v[j] = v;
     if (a.ema) a.ema[j] = e;
   }
@@ -194,7 +267,8 @@ extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v
                                     float lr, const float *lr_dev, float beta1, float beta2, float eps,
                                     float weight_decay, int32_t step, const int32_t *step_dev, float max_norm,
                                     const float *sumsq_parts, int32_t n_parts, float grad_mul,
-                                    float ema_decay, stdadk_stream_t stream) {
+                                    float ema_decay, const stdadk_bf16_shadow *shadow,
+                                    stdadk_stream_t stream) {
   STDADK_REQUIRE(n >= 0, STDADK_E_ARG, "adamw: negative n");
   if (n == 0) return 0;
   STDADK_REQUIRE(p && g && m && v, STDADK_E_ARG, "adamw: NULL pointer");
@@ -204,6 +278,10 @@ extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v
   a.p = p; a.g = g; a.m = m; a.v = v; a.ema = ema; a.n = n; a.lr = lr; a.lr_dev = lr_dev;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.step = step; a.step_dev = step_dev;
   a.max_norm = max_norm; a.sumsq = sumsq_parts; a.n_parts = n_parts; a.grad_mul = grad_mul; a.ema_decay = ema_decay;
+  if (int rc = fill_shadow(a.sh, shadow, p, n)) return rc;
+  STDADK_REQUIRE(a.sh.n == 0 || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                                  reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(ema)) & 15) == 0,
+                 STDADK_E_ALIGN, "adamw: bf16 shadows need 16-byte aligned buffers");
   int64_t blocks = ceil_div(n, 256 * 4);
   if (blocks > 4096) blocks = 4096;
   STDADK_LAUNCH(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -220,6 +298,22 @@ static int fill_group(AdamArgs &a, const stdadk_adam_group *gr, float beta1, flo
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.step = step; a.step_dev = step_dev;
   a.max_norm = gr->max_norm; a.sumsq = gr->sumsq_parts; a.n_parts = gr->n_parts; a.grad_mul = grad_mul;
   a.ema_decay = ema_decay;
+  if (int rc = fill_shadow(a.sh, gr->shadow, gr->p, gr->n)) return rc;
+  STDADK_REQUIRE(a.sh.n == 0 || ((reinterpret_cast<uintptr_t>(gr->g) | reinterpret_cast<uintptr_t>(gr->m) |
+                                  reinterpret_cast<uintptr_t>(gr->v) | reinterpret_cast<uintptr_t>(gr->ema)) & 15) == 0,
+                 STDADK_E_ALIGN, "adamw2: bf16 shadows need 16-byte aligned buffers");
+  return 0;
+}
+
+extern "C" int stdadk_bf16_shadow_refresh(const float *p, const stdadk_bf16_shadow *shadow, stdadk_stream_t stream) {
+  STDADK_REQUIRE(p && shadow, STDADK_E_ARG, "bf16_shadow_refresh: NULL pointer");
+  ShadowArgs sh;
+  if (int rc = fill_shadow(sh, shadow, p, -1)) return rc;
+  if (sh.n == 0) return 0;
+  int64_t blocks = ceil_div((sh.hi - sh.lo) / 4, 256);
+  if (blocks > 1024) blocks = 1024;
+  STDADK_LAUNCH(shadow_refresh_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, sh);
+  STDADK_CHECK_LAUNCH("bf16_shadow_refresh");
   return 0;
 }
 

@@ -15,6 +15,8 @@ constexpr int TAIL_MAX_W = 256;                      // widest layer the LDS pla
 constexpr int TAIL_MAXQ = 8;
 
 struct TailLayer {
+  const uint16_t *Wbf;   // STDADK_FLAG_BF16: bf16 copy of W [h][hp], and of its transpose [hp][h] (the operand of
+  const uint16_t *WTbf;  // dA = dZ W); NULL otherwise
   const float *W;      // [h][hp]  (nn.Linear layout)
   const float *b;      // [h]
   const float *g;      // LayerNorm gamma / beta or NULL
@@ -68,6 +70,7 @@ struct TailFwdArgs {
   float eps, drop_p;
   uint64_t seed;
   const int *step_dev;
+  int bf16;                     // STDADK_FLAG_BF16: the layers' GEMMs take bf16 operands (L[i].Wbf)
   unsigned long long *stamps;   // -DSTDADK_DIAG builds only: [blocks][16] wall-clock stamps (100 MHz), else NULL
 };
 
@@ -87,13 +90,16 @@ struct TailBwdArgs {
   float drop_p;
   uint64_t seed;
   const int *step_dev;
+  int bf16;                     // STDADK_FLAG_BF16: dA = dZ W with bf16 operands (L[i].WTbf)
   unsigned long long *stamps;   // -DSTDADK_DIAG builds only (see TailFwdArgs), else NULL
 };
 
 bool tail_supported(const stdadk_mlp_desc *d, int first_layer);
-int tail_rows(int64_t B);        // rows per workgroup the launches will use for a batch of B rows
+// rows per workgroup the launches will use for a batch of B rows (`cap32`: bf16 operands together with the dense
+// layer 0 inside the launch keep three activation images in LDS, which fit for at most 32 rows)
+int tail_rows(int64_t B, bool cap32 = false);
 int tail_forward(const TailFwdArgs &a, hipStream_t st);
-int tail_backward(const TailBwdArgs &a, hipStream_t st);
+int tail_backward(const TailBwdArgs &a, hipStream_t st, bool cap32 = false);
 // training: forward (with the loss) and backward of every row tile in one launch
 int tail_forward_backward(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st);
 

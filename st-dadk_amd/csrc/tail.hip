@@ -11,18 +11,18 @@
 
 namespace stdadk {
 
-// D0: the launch starts from the raw observations (TailDense0 in tail.h)
-template <int MT, bool D0>
+// D0: the launch starts from the raw observations (TailDense0 in tail.h); BF: bf16 operands (STDADK_FLAG_BF16)
+template <int MT, bool D0, bool BF>
 __global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[TT / 64];
-  tail_fwd_body<MT, D0>(a, smem, red, blockIdx.x);
+  tail_fwd_body<MT, D0, BF>(a, smem, red, blockIdx.x);
 }
 
-template <int MT>
+template <int MT, bool BF>
 __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  tail_bwd_body<MT>(a, smem, blockIdx.x);
+  tail_bwd_body<MT, BF>(a, smem, blockIdx.x);
 }
 
 // Training step: the forward chain, the loss and the backward chain of a row tile are all row-local, so
@@ -30,13 +30,13 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
 // what the forward just wrote in L2).  The forward's global stores (xhat, act, rstd, dY) are complete
 // and visible to the whole workgroup after the __syncthreads() (vmcnt(0) + barrier); none of those lines
 // was read by this CU earlier in the launch, so no stale copy can sit in its L1.
-template <int MT, bool D0>
+template <int MT, bool D0, bool BF>
 __global__ __launch_bounds__(TT) void tail_fwd_bwd_kernel(TailFwdArgs f, TailBwdArgs b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[TT / 64];
-  tail_fwd_body<MT, D0>(f, smem, red, blockIdx.x);
+  tail_fwd_body<MT, D0, BF>(f, smem, red, blockIdx.x);
   __syncthreads();
-  tail_bwd_body<MT>(b, smem, blockIdx.x);
+  tail_bwd_body<MT, BF>(b, smem, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -48,20 +48,34 @@ bool tail_supported(const stdadk_mlp_desc *d, int first_layer) {
   return true;
 }
 
-static size_t fwd_lds(int R) { return (size_t)(2 * R * ACT_LD) * sizeof(float); }
-static size_t bwd_lds(int R) {
-  const bool alias = (size_t)R * ACT_LD >= (size_t)3 * NW * 256;
-  return (size_t)(2 * R * ACT_LD + (alias ? 0 : 3 * NW * 256) + R * TAIL_MAXQ) * sizeof(float);
+// bf16 operands: one fp32 tile + the bf16 image (with the dense layer 0: the fp32 pair + the image)
+static size_t fwd_lds(int R, bool d0, bool bf) {
+  if (!bf) return (size_t)(2 * R * ACT_LD) * sizeof(float);
+  return (size_t)((d0 ? 2 : 1) * R * ACT_LD) * sizeof(float) + (size_t)R * ABF_LD * sizeof(u16);
 }
+static size_t bwd_lds(int R, bool bf) {
+  if (bf) return (R == 64 ? tail_bwd_lds_floats<4, true>() : (R == 32 ? tail_bwd_lds_floats<2, true>() : tail_bwd_lds_floats<1, true>())) * sizeof(float);
+  return (R == 64 ? tail_bwd_lds_floats<4, false>() : (R == 32 ? tail_bwd_lds_floats<2, false>() : tail_bwd_lds_floats<1, false>())) * sizeof(float);
+}
+static_assert(tail_bwd_lds_floats<4, true>() * sizeof(float) <= 160 * 1024, "bf16 backward tile does not fit the LDS");
 
-int tail_rows(int64_t B) {
+int tail_rows(int64_t B, bool cap32) {
   // two or four 16-row tiles per workgroup (shared weight fragments) once that still gives every CU
   // a workgroup; one tile per workgroup for small batches
   static const int forced = [] { const char *e = getenv("STDADK_TAIL_ROWS"); return e ? atoi(e) : 0; }();
-  if (forced == 16 || forced == 32 || forced == 64) return forced;      // measurement aid
+  if (forced == 16 || forced == 32 || (forced == 64 && !cap32)) return forced;      // measurement aid
   // (MI355X, C2 widths: 64 rows +5 % step throughput at B = 16 384 and 65 536 over 32 rows)
-  if (ceil_div(B, 64) >= 256) return 64;
+  if (ceil_div(B, 64) >= 256 && !cap32) return 64;
   return ceil_div(B, 32) >= 256 ? 32 : 16;
+}
+
+static int check_bf(int bf16, int n, const TailLayer *L, bool fwd, int first) {
+  if (!bf16) return 0;
+  for (int i = first; i < n; ++i)
+    STDADK_REQUIRE((fwd ? L[i].Wbf : L[i].WTbf) != nullptr && (reinterpret_cast<uintptr_t>(fwd ? L[i].Wbf : L[i].WTbf) & 15) == 0,
+                   STDADK_E_ARG, "tail: STDADK_FLAG_BF16 needs the 16-byte aligned bf16 weight copies of every layer after "
+                   "the first (params->W_bf16 / WT_bf16; stdadk_bf16_shadow_refresh)");
+  return 0;
 }
 
 static int check_d0(const TailFwdArgs &a) {
@@ -81,74 +95,91 @@ static int check_d0(const TailFwdArgs &a) {
   return 0;
 }
 
-template <int MT, bool D0>
+template <int MT, bool D0, bool BF>
 static int launch_fwd(const TailFwdArgs &a, hipStream_t st) {
   constexpr int R = 16 * MT;
   static bool attr_done = false;
   if (!attr_done) {   // once per process, never inside a stream capture (the first step runs eagerly)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel<MT, D0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds(R));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel<MT, D0, BF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds(R, D0, BF));
     if (e != hipSuccess) { set_error("tail_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  STDADK_LAUNCH_NAMED(D0 ? "tail_fwd_kernel<dense0>" : "tail_fwd_kernel", (tail_fwd_kernel<MT, D0>),
-                      dim3((unsigned)ceil_div(a.B, R)), dim3(TT), fwd_lds(R), st, a);
+  STDADK_LAUNCH_NAMED(D0 ? (BF ? "tail_fwd_kernel<dense0,bf16>" : "tail_fwd_kernel<dense0>") : (BF ? "tail_fwd_kernel<bf16>" : "tail_fwd_kernel"),
+                      (tail_fwd_kernel<MT, D0, BF>), dim3((unsigned)ceil_div(a.B, R)), dim3(TT), fwd_lds(R, D0, BF), st, a);
   STDADK_CHECK_LAUNCH("tail_forward");
   return 0;
 }
 
+// dispatch on (rows, dense layer 0, bf16 operands); the bf16 + dense-0 combination is built for <= 32 rows
+#define TAIL_DISPATCH(FN, r, d0, bf, ...)                                                                    \
+  ((bf) ? ((d0) ? ((r) == 32 ? FN<2, true, true>(__VA_ARGS__) : FN<1, true, true>(__VA_ARGS__))              \
+                : ((r) == 64 ? FN<4, false, true>(__VA_ARGS__)                                               \
+                             : ((r) == 32 ? FN<2, false, true>(__VA_ARGS__) : FN<1, false, true>(__VA_ARGS__)))) \
+        : ((d0) ? ((r) == 64 ? FN<4, true, false>(__VA_ARGS__)                                               \
+                             : ((r) == 32 ? FN<2, true, false>(__VA_ARGS__) : FN<1, true, false>(__VA_ARGS__))) \
+                : ((r) == 64 ? FN<4, false, false>(__VA_ARGS__)                                              \
+                             : ((r) == 32 ? FN<2, false, false>(__VA_ARGS__) : FN<1, false, false>(__VA_ARGS__)))))
+
 int tail_forward(const TailFwdArgs &a, hipStream_t st) {
-  const int r = tail_rows(a.B);
+  const bool d0 = a.d0.on != 0, bf = a.bf16 != 0;
+  const int r = tail_rows(a.B, bf && d0);
   if (int rc = check_d0(a)) return rc;
-  if (a.d0.on) return r == 64 ? launch_fwd<4, true>(a, st) : (r == 32 ? launch_fwd<2, true>(a, st) : launch_fwd<1, true>(a, st));
-  return r == 64 ? launch_fwd<4, false>(a, st) : (r == 32 ? launch_fwd<2, false>(a, st) : launch_fwd<1, false>(a, st));
+  if (int rc = check_bf(a.bf16, a.n_layers, a.L, true, 0)) return rc;
+  return TAIL_DISPATCH(launch_fwd, r, d0, bf, a, st);
 }
 
-template <int MT>
+template <int MT, bool BF>
 static int launch_bwd(const TailBwdArgs &a, hipStream_t st) {
   constexpr int R = 16 * MT;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel<MT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds(R));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel<MT, BF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds(R, BF));
     if (e != hipSuccess) { set_error("tail_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  STDADK_LAUNCH_NAMED("tail_bwd_kernel", (tail_bwd_kernel<MT>), dim3((unsigned)ceil_div(a.B, R)), dim3(TT), bwd_lds(R), st, a);
+  STDADK_LAUNCH_NAMED(BF ? "tail_bwd_kernel<bf16>" : "tail_bwd_kernel", (tail_bwd_kernel<MT, BF>),
+                      dim3((unsigned)ceil_div(a.B, R)), dim3(TT), bwd_lds(R, BF), st, a);
   STDADK_CHECK_LAUNCH("tail_backward");
   return 0;
 }
 
-template <int MT, bool D0>
+template <int MT, bool D0, bool BF>
 static int launch_fwd_bwd(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st) {
   constexpr int R = 16 * MT;
-  const size_t lds = fwd_lds(R) > bwd_lds(R) ? fwd_lds(R) : bwd_lds(R);
+  const size_t lds = fwd_lds(R, D0, BF) > bwd_lds(R, BF) ? fwd_lds(R, D0, BF) : bwd_lds(R, BF);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_bwd_kernel<MT, D0>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_bwd_kernel<MT, D0, BF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("tail_forward_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  STDADK_LAUNCH_NAMED(D0 ? "tail_fwd_bwd_kernel<dense0>" : "tail_fwd_bwd_kernel", (tail_fwd_bwd_kernel<MT, D0>),
-                      dim3((unsigned)ceil_div(f.B, R)), dim3(TT), lds, st, f, b);
+  STDADK_LAUNCH_NAMED(D0 ? (BF ? "tail_fwd_bwd_kernel<dense0,bf16>" : "tail_fwd_bwd_kernel<dense0>")
+                         : (BF ? "tail_fwd_bwd_kernel<bf16>" : "tail_fwd_bwd_kernel"),
+                      (tail_fwd_bwd_kernel<MT, D0, BF>), dim3((unsigned)ceil_div(f.B, R)), dim3(TT), lds, st, f, b);
   STDADK_CHECK_LAUNCH("tail_forward_backward");
   return 0;
 }
 
 int tail_forward_backward(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st) {
-  const int r = tail_rows(f.B);
+  const bool d0 = f.d0.on != 0, bf = f.bf16 != 0;
+  STDADK_REQUIRE((f.bf16 != 0) == (b.bf16 != 0), STDADK_E_ARG, "tail: forward and backward disagree on bf16 operands");
+  const int r = tail_rows(f.B, bf && d0);
   if (int rc = check_d0(f)) return rc;
-  if (f.d0.on)
-    return r == 64 ? launch_fwd_bwd<4, true>(f, b, st)
-                   : (r == 32 ? launch_fwd_bwd<2, true>(f, b, st) : launch_fwd_bwd<1, true>(f, b, st));
-  return r == 64 ? launch_fwd_bwd<4, false>(f, b, st)
-                 : (r == 32 ? launch_fwd_bwd<2, false>(f, b, st) : launch_fwd_bwd<1, false>(f, b, st));
+  if (int rc = check_bf(f.bf16, f.n_layers, f.L, true, 0)) return rc;
+  if (int rc = check_bf(b.bf16, b.n_layers, b.L, false, 1)) return rc;
+  return TAIL_DISPATCH(launch_fwd_bwd, r, d0, bf, f, b, st);
 }
 
-int tail_backward(const TailBwdArgs &a, hipStream_t st) {
-  const int r = tail_rows(a.B);
-  return r == 64 ? launch_bwd<4>(a, st) : (r == 32 ? launch_bwd<2>(a, st) : launch_bwd<1>(a, st));
+// `cap32`: the forward of this batch ran with the dense layer 0 and bf16 operands (32-row tiles at most); the
+// partial buffers of both kernels are indexed by the same tile size
+int tail_backward(const TailBwdArgs &a, hipStream_t st, bool cap32) {
+  const int r = tail_rows(a.B, cap32);
+  if (int rc = check_bf(a.bf16, a.n_layers, a.L, false, 1)) return rc;
+  if (a.bf16) return r == 64 ? launch_bwd<4, true>(a, st) : (r == 32 ? launch_bwd<2, true>(a, st) : launch_bwd<1, true>(a, st));
+  return r == 64 ? launch_bwd<4, false>(a, st) : (r == 32 ? launch_bwd<2, false>(a, st) : launch_bwd<1, false>(a, st));
 }
 
 }  // namespace stdadk

@@ -121,6 +121,72 @@ __device__ __forceinline__ void preload_w_kn(BFrag<1> &f, const float *__restric
   if (wave < (N >> 4)) load_bfrag_kn(f, Wkn, N, K, 0, wave, c16, q);
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 operands (STDADK_FLAG_BF16): v_mfma_f32_16x16x32_bf16, fp32 accumulate
+// ---------------------------------------------------------------------------------------------
+// Lane l = 16 q + c16 holds A[row c16][k = 8q + j] and B[k = 8q + j][col c16], j = 0..7 (one 16-byte piece
+// each); D as for the fp32 form.  A 64-deep chunk is TWO MFMAs: lane group q owns the 16 consecutive k
+// 64c + 16q .. +15 of its row (A: the bf16 activation image in LDS; B: row n of the [N][K] bf16 weights), the
+// first MFMA takes its low 8, the second its high 8 -- any assignment of k to (MFMA, q, j) sums the same
+// products as long as A and B agree on it, and this one makes each weight row's four pieces one full 128-byte line.
+typedef unsigned short u16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int ABF_LD = TAIL_MAX_W + 8;        // bf16 activation row stride in LDS (elements; 528 B, 16-byte aligned)
+
+__device__ __forceinline__ f32x4 mfma16h(uint4 a, uint4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 v = {(__bf16)a, (__bf16)b};       // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ u16 to_bf16(float a) { return (u16)(pack_bf16(a, 0.f) & 0xffffu); }
+
+struct BFragH { uint4 v[2]; };          // this lane's 16 k of weight row n in chunk c
+
+// unconditional loads from clamped addresses like load_bfrag; a piece beyond K meets zeros in the A image
+__device__ __forceinline__ void load_bfrag_h(BFragH &f, const u16 *__restrict__ Wn, int K, int c, int wave, int c16, int q) {
+  const int n = 16 * wave + c16;                      // < N by the caller's wave < N/16 test
+  const int k = 64 * c + 16 * q;
+  const uint4 *src = reinterpret_cast<const uint4 *>(Wn + (size_t)n * K + (k < K ? k : 0));
+  f.v[0] = src[0]; f.v[1] = src[1];
+}
+
+template <int MT>
+__device__ __forceinline__ void mma_chunk_h(f32x4 (*acc)[MAX_NI], const BFragH &f, const u16 *__restrict__ A, int c, int c16,
+                                            int q) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const uint4 *ap = reinterpret_cast<const uint4 *>(A + (16 * mt + c16) * ABF_LD + 64 * c + 16 * q);
+    const uint4 a0 = ap[0], a1 = ap[1];
+    acc[mt][0] = mfma16h(a0, f.v[0], acc[mt][0]);
+    acc[mt][0] = mfma16h(a1, f.v[1], acc[mt][0]);
+  }
+}
+
+__device__ __forceinline__ void preload_wh(BFragH &f, const u16 *__restrict__ Wn, int N, int K, int wave, int c16, int q) {
+  if (wave < (N >> 4)) load_bfrag_h(f, Wn, K, 0, wave, c16, q);
+}
+
+// acc[mt][0] += A[R x K] (bf16 image in LDS, columns K .. 64 ceil(K/64) zero) * W^T, W = [N][K] bf16 in global
+// memory, chunk 0 already in registers (preload_wh), two chunks in flight
+template <int MT>
+__device__ __forceinline__ void gemm16_pre_h(f32x4 (*acc)[MAX_NI], const u16 *__restrict__ A, const u16 *__restrict__ Wn,
+                                             int N, int K, int wave, int c16, int q, BFragH &f0) {
+  if (wave >= (N >> 4)) return;
+  const int nchunk = (K + 63) >> 6;
+  BFragH f1;
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 1 < nchunk) load_bfrag_h(f1, Wn, K, c + 1, wave, c16, q);
+    mma_chunk_h<MT>(acc, f0, A, c, c16, q);
+    if (c + 1 < nchunk) {
+      if (c + 2 < nchunk) load_bfrag_h(f0, Wn, K, c + 2, wave, c16, q);
+      mma_chunk_h<MT>(acc, f1, A, c + 1, c16, q);
+    }
+  }
+}
+
 // GEMM of a phase: acc[mt][0] (rows 16 mt.., N tile of this wave) += A[R x K] (LDS, row stride ACT_LD) * W.
 // M = 16..64 rows is the GEMV-like regime: every wave streams ITS OWN slice of W straight into VGPRs (no
 // LDS staging, no workgroup barrier in the K loop), two 32-deep chunks in flight.
@@ -202,23 +268,32 @@ __device__ __forceinline__ void d0_gemm(f32x4 (*acc)[MAX_NI], const float *act0,
 #else
 #define STAMP(i) do { } while (0)
 #endif
-template <int MT, bool D0 = false>
+// BF: the layers' GEMMs take bf16 operands (fp32 accumulate; LayerNorm, loss and everything kept for the backward
+// stay fp32).  LDS then holds ONE fp32 tile (z / LayerNorm in place; the head reads it) and the bf16 image of the
+// current activations in the place of the second fp32 tile -- with D0 the fp32 pair stays (the features of layer 0
+// use both halves) and the image follows them.
+template <int MT, bool D0 = false, bool BF = false>
 __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem, float *red, const int tile) {
   constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
-  float *act0 = smem, *act1 = smem + R * ACT_LD;
+  float *act0 = smem, *act1 = (BF && !D0) ? smem : smem + R * ACT_LD;
+  u16 *abf = reinterpret_cast<u16 *>(smem + (D0 ? 2 : 1) * R * ACT_LD);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = tile * R;
   STAMP(0);
   BFrag<1> wpre;
+  BFragH wpre_h;
   if constexpr (D0) {
     if (a.d0.on == 1) {
       if (wave < (a.d0.L0.h >> 4)) d0_load_bfrag(wpre, a.d0.W0T, a.d0.L0.h, a.d0.L0.hp, 0, wave, c16, q);
       d0_fill_features<MT>(a.d0, act0, act1, row0, a.B);
     }
   } else {
-    if (a.n_layers > 0) preload_w(wpre, a.L[0].W, a.L[0].h, a.L[0].hp, wave, c16, q);
+    if (a.n_layers > 0) {
+      if constexpr (BF) preload_wh(wpre_h, a.L[0].Wbf, a.L[0].h, a.L[0].hp, wave, c16, q);
+      else preload_w(wpre, a.L[0].W, a.L[0].h, a.L[0].hp, wave, c16, q);
+    }
   }
   if constexpr (!D0) {
     // input tile: unconditional loads from clamped rows (rows >= B duplicate the last row; nothing
@@ -238,6 +313,16 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
       if (idx < R * v4) {
         const int row = idx / v4, c4 = idx - row * v4;
         *reinterpret_cast<float4 *>(act0 + row * ACT_LD + 4 * c4) = tv[i];
+        if constexpr (BF)
+          *reinterpret_cast<uint2 *>(abf + row * ABF_LD + 4 * c4) = make_uint2(pack_bf16(tv[i].x, tv[i].y), pack_bf16(tv[i].z, tv[i].w));
+      }
+    }
+    if constexpr (BF) {
+      // the image's columns h_in .. 255 are zero: a 64-deep chunk may reach past K
+      const int z4 = (TAIL_MAX_W - a.h_in) >> 2;
+      for (int idx = tid; idx < R * z4; idx += TT) {
+        const int row = idx / z4, c4 = idx - row * z4;
+        *reinterpret_cast<uint2 *>(abf + row * ABF_LD + a.h_in + 4 * c4) = make_uint2(0u, 0u);
       }
     }
   }
@@ -289,9 +374,13 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
       d0_gemm<MT>(acc, act0, act1, a.d0.W0T, h, hp, wave, c16, q, wpre);
       if (hp > TAIL_MAX_W) lds_barrier();        // z goes into act1, which held the second half of the features
     } else {
-      gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre);
+      if constexpr (BF) gemm16_pre_h<MT>(acc, abf, L.Wbf, h, hp, wave, c16, q, wpre_h);
+      else gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre);
     }
-    if (li + 1 < a.n_layers) preload_w(wpre, a.L[li + 1].W, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q);
+    if (li + 1 < a.n_layers) {
+      if constexpr (BF) preload_wh(wpre_h, a.L[li + 1].Wbf, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q);
+      else preload_w(wpre, a.L[li + 1].W, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q);
+    }
     STAMP(2 + 4 * (li < 0 ? 0 : li));
     // z = acc + bias into the other activation buffer
 #pragma unroll
@@ -350,6 +439,7 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
             L.act[(size_t)grow * h + col] = v;
           }
         }
+        if constexpr (BF) abf[row * ABF_LD + col] = col < h ? to_bf16(v) : (u16)0;     // next layer's A operand
       }
     }
     STAMP(4 + 4 * (li < 0 ? 0 : li));
@@ -417,14 +507,25 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
 // ---------------------------------------------------------------------------------------------
 // backward (data path): dA / dZ of every hidden layer + column partials for dgamma, dbeta, db
 // ---------------------------------------------------------------------------------------------
-template <int MT>
+// LDS floats of the backward body (the launch code sizes the dynamic segment with it)
+template <int MT, bool BF>
+constexpr size_t tail_bwd_lds_floats() {
+  constexpr size_t R = 16 * MT;
+  if (BF) return R * ACT_LD + (R * ABF_LD + 1) / 2 + 3 * NW * 256 + R * TAIL_MAXQ;
+  return 2 * R * ACT_LD + (R * ACT_LD >= (size_t)3 * NW * 256 ? 0 : 3 * NW * 256) + R * TAIL_MAXQ;
+}
+
+// BF: dA = dZ W with bf16 operands (the transposed weight copies WTbf as the K-contiguous operand): ONE fp32
+// gradient tile (LayerNorm backward in place, the GEMM's output lands in it again) + the bf16 image of dZ.
+template <int MT, bool BF = false>
 __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem, const int tile) {
   constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
-  float *d0 = smem, *d1 = smem + R * ACT_LD;
+  float *d0 = smem, *d1 = BF ? smem : smem + R * ACT_LD;
+  u16 *abf = reinterpret_cast<u16 *>(smem + R * ACT_LD);
   // column-partial scratch [3][NW][256]: with 64 rows the spare activation buffer is large enough and
   // free during the LayerNorm phase, so it is aliased there instead of taking another 48 KiB
-  constexpr bool RED_ALIAS = (size_t)R * ACT_LD >= (size_t)3 * NW * 256;
-  float *red_own = smem + 2 * R * ACT_LD;
+  constexpr bool RED_ALIAS = !BF && (size_t)R * ACT_LD >= (size_t)3 * NW * 256;
+  float *red_own = BF ? smem + R * ACT_LD + (R * ABF_LD + 1) / 2 : smem + 2 * R * ACT_LD;
   float *sdy = red_own + (RED_ALIAS ? 0 : 3 * NW * 256);   // [R][TAIL_MAXQ]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -507,7 +608,11 @@ __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem,
     const TailLayer &L = a.L[li];
     const int h = L.h;
     BFrag<1> wpre;
-    if (li > 0) preload_w_kn(wpre, L.W, L.hp, h, wave, c16, q);       // for the dA GEMM at the end of this pass
+    BFragH wpre_h;
+    if (li > 0) {                                                       // for the dA GEMM at the end of this pass
+      if constexpr (BF) preload_wh(wpre_h, L.WTbf, L.hp, h, wave, c16, q);
+      else preload_w_kn(wpre, L.W, L.hp, h, wave, c16, q);
+    }
     // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows RPW*w .. of this wave.  Its global inputs
     // (xhat rows, gamma, beta, rstd) were requested one phase early (ln_inputs below).
     float pg[4], pb[4], pz[4];
@@ -554,6 +659,9 @@ __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem,
           cur[row * ACT_LD + col] = dz;
           if (valid) a.dZ[li][(size_t)grow * h + col] = dz;
           pz[cc] += dz;
+          if constexpr (BF) abf[row * ABF_LD + col] = to_bf16(dz);
+        } else if constexpr (BF) {
+          abf[row * ABF_LD + col] = (u16)0;          // columns h .. 255 of the image: zero (64-deep chunks)
         }
       }
     }
@@ -588,7 +696,8 @@ __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem,
       for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ln_inputs(a.L[li - 1]);        // consumed after the GEMM, in the next pass
     lds_barrier();                 // every wave's dZ rows are in `cur`
-    gemm16_pre<MT, true>(acc, cur, L.W, hp, h, wave, c16, q, wpre);
+    if constexpr (BF) gemm16_pre_h<MT>(acc, abf, L.WTbf, hp, h, wave, c16, q, wpre_h);
+    else gemm16_pre<MT, true>(acc, cur, L.W, hp, h, wave, c16, q, wpre);
     STAMP(3 + 3 * (a.n_layers - 1 - li));      // dA GEMM of this pass
 #pragma unroll
     for (int i = 0; i < MAX_NI; ++i) {

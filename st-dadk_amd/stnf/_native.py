@@ -28,7 +28,17 @@ class MlpDesc(C.Structure):
 
 class MlpTensors(C.Structure):
     _fields_ = [("W", C.c_void_p * (MAX_HIDDEN + 1)), ("b", C.c_void_p * (MAX_HIDDEN + 1)),
-                ("ln_g", C.c_void_p * MAX_HIDDEN), ("ln_b", C.c_void_p * MAX_HIDDEN)]
+                ("ln_g", C.c_void_p * MAX_HIDDEN), ("ln_b", C.c_void_p * MAX_HIDDEN),
+                ("W_bf16", C.c_void_p * (MAX_HIDDEN + 1)), ("WT_bf16", C.c_void_p * (MAX_HIDDEN + 1))]
+
+
+class BF16Region(C.Structure):
+    _fields_ = [("off", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("dst", C.c_void_p),
+                ("dst_t", C.c_void_p)]
+
+
+class BF16Shadow(C.Structure):
+    _fields_ = [("n", C.c_int32), ("r", BF16Region * MAX_HIDDEN)]
 
 
 class BasisDesc(C.Structure):
@@ -55,13 +65,14 @@ class OptimDesc(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_float), ("lr_dev", C.c_void_p), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step_dev", C.c_void_p),
-                ("max_norm", C.c_float), ("sumsq_parts", C.c_void_p), ("ema_decay", C.c_float)]
+                ("max_norm", C.c_float), ("sumsq_parts", C.c_void_p), ("ema_decay", C.c_float),
+                ("shadow", C.POINTER(BF16Shadow))]
 
 
 class AdamGroup(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_float), ("lr_dev", C.c_void_p), ("max_norm", C.c_float),
-                ("sumsq_parts", C.c_void_p), ("n_parts", C.c_int32)]
+                ("sumsq_parts", C.c_void_p), ("n_parts", C.c_int32), ("shadow", C.POINTER(BF16Shadow))]
 
 
 SPARSITY_KINDS = {"none": 0, "element": 1, "group": 2, "sparse_group": 3}
@@ -84,6 +95,7 @@ FLAG_W0_T = 2
 FLAG_LOG_BW = 4
 FLAG_WINDOW = 8
 FLAG_PREBINNED = 16
+FLAG_BF16 = 32
 
 _lib = None
 
@@ -183,7 +195,9 @@ _SIGNATURES = {
     "stdadk_adamw_ema_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_float, C.c_void_p, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float,
-                                       C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
+                                       C.c_void_p, C.c_int32, C.c_float, C.c_float, C.POINTER(BF16Shadow),
+                                       C.c_void_p]),
+    "stdadk_bf16_shadow_refresh": (C.c_int, [C.c_void_p, C.POINTER(BF16Shadow), C.c_void_p]),
 }
 
 
@@ -223,7 +237,7 @@ def _dev(tensor, name):
     if not tensor.is_cuda:
         raise RuntimeError(f"{name}: expected a tensor on a HIP device (cuda:N), got {tensor.device}; "
                            f"the MI355X build of stnf has no CPU path")
-    if tensor.dtype != torch.float32 and tensor.dtype != torch.uint8 and tensor.dtype != torch.int32:
+    if tensor.dtype not in (torch.float32, torch.uint8, torch.int32, torch.bfloat16):
         raise RuntimeError(f"{name}: unsupported dtype {tensor.dtype}")
     if not tensor.is_contiguous():
         raise RuntimeError(f"{name}: tensor must be contiguous")
@@ -279,15 +293,40 @@ def make_desc(in_dim, hidden, out_dim, layernorm, dropout_p, ln_eps=1e-5):
     return d
 
 
-def make_tensors(Ws, bs, gs, betas):
-    """Pack per-layer tensors (lists; gs/betas may be None) into the ABI struct."""
+def make_tensors(Ws, bs, gs, betas, bf16=None):
+    """Pack per-layer tensors (lists; gs/betas may be None) into the ABI struct.  `bf16`: per Linear index
+    None or the pair (W_bf16 (out,in), WT_bf16 (in,out)) of torch.bfloat16 operand copies (FLAG_BF16)."""
     s = MlpTensors()
     for i, (w, b) in enumerate(zip(Ws, bs)):
         s.W[i], s.b[i] = _dev(w, f"W[{i}]"), _dev(b, f"b[{i}]")
     if gs is not None:
         for i, (g, be) in enumerate(zip(gs, betas)):
             s.ln_g[i], s.ln_b[i] = _dev(g, f"ln_g[{i}]"), _dev(be, f"ln_b[{i}]")
+    if bf16 is not None:
+        for i, pair in enumerate(bf16):
+            if pair is not None:
+                if pair[0].dtype != torch.bfloat16 or pair[1].dtype != torch.bfloat16:
+                    raise RuntimeError("make_tensors: the operand copies must be torch.bfloat16")
+                s.W_bf16[i], s.WT_bf16[i] = _dev(pair[0], f"W_bf16[{i}]"), _dev(pair[1], f"WT_bf16[{i}]")
     return s
+
+
+def make_bf16_shadow(regions):
+    """stdadk_bf16_shadow from [(element offset into the flat fp32 buffer, rows, cols, dst, dst_t)]."""
+    if len(regions) > MAX_HIDDEN:
+        raise RuntimeError(f"at most {MAX_HIDDEN} bf16 shadow regions")
+    sh = BF16Shadow()
+    sh.n = len(regions)
+    for i, (off, rows, cols, dst, dst_t) in enumerate(regions):
+        sh.r[i].off, sh.r[i].rows, sh.r[i].cols = int(off), int(rows), int(cols)
+        sh.r[i].dst, sh.r[i].dst_t = _dev(dst, "shadow dst"), _dev(dst_t, "shadow dst_t")
+    return sh
+
+
+def bf16_shadow_refresh(p, shadow):
+    """Rewrite every region's bf16 copies from the fp32 buffer `p` (stdadk_bf16_shadow_refresh)."""
+    rc = lib().stdadk_bf16_shadow_refresh(_dev(p, "p"), C.byref(shadow), _stream())
+    _check(rc, "stdadk_bf16_shadow_refresh")
 
 
 def mlp_workspace_bytes(desc, B):
@@ -641,18 +680,22 @@ def step_advance(step_dev):
 
 
 def adamw_ema(p, g, m, v, ema, lr, betas, eps, weight_decay, step, max_norm=0.0, sumsq_parts=None,
-              grad_mul=1.0, ema_decay=0.0, lr_dev=None, step_dev=None):
+              grad_mul=1.0, ema_decay=0.0, lr_dev=None, step_dev=None, shadow=None):
     rc = lib().stdadk_adamw_ema_f32(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"),
                                     _dev(ema, "ema"), p.numel(), lr, _dev(lr_dev, "lr_dev"),
                                     betas[0], betas[1], eps, weight_decay, int(step),
                                     _dev(step_dev, "step_dev"), max_norm, _dev(sumsq_parts, "sumsq"),
                                     0 if sumsq_parts is None else sumsq_parts.numel(),
-                                    grad_mul, ema_decay, _stream())
+                                    grad_mul, ema_decay, C.byref(shadow) if shadow is not None else None,
+                                    _stream())
     _check(rc, "stdadk_adamw_ema_f32")
 
 
-def make_optim(p, g, m, v, ema, lr, lr_dev, betas, eps, weight_decay, step_dev, max_norm, sumsq_parts, ema_decay):
+def make_optim(p, g, m, v, ema, lr, lr_dev, betas, eps, weight_decay, step_dev, max_norm, sumsq_parts, ema_decay,
+               shadow=None):
     o = OptimDesc()
+    o._keep = shadow                 # the descriptor points at it
+    o.shadow = C.pointer(shadow) if shadow is not None else None
     o.p, o.g, o.m, o.v, o.ema = _dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), _dev(ema, "ema")
     o.n = p.numel()
     o.lr, o.lr_dev = float(lr), _dev(lr_dev, "lr_dev")
@@ -690,8 +733,10 @@ def sumsq2(g0, parts0, g1, parts1, step_inc=None):
     _check(rc, "stdadk_sumsq2_f32")
 
 
-def make_adam_group(p, g, m, v, ema, lr, lr_dev=None, max_norm=0.0, sumsq_parts=None):
+def make_adam_group(p, g, m, v, ema, lr, lr_dev=None, max_norm=0.0, sumsq_parts=None, shadow=None):
     gr = AdamGroup()
+    gr._keep = shadow
+    gr.shadow = C.pointer(shadow) if shadow is not None else None
     gr.p, gr.g, gr.m, gr.v, gr.ema = _dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), _dev(ema, "ema")
     gr.n = p.numel()
     gr.lr, gr.lr_dev = float(lr), _dev(lr_dev, "lr_dev")

@@ -137,8 +137,11 @@ class TrainStep:
                  non_crossing_lambda=0.0, basis_lr_ratio=0.05, basis_clip_ratio=0.1,
                  domain_penalty_weight=0.0, movement_penalty_weight=0.0, sparsity_penalty_type="none",
                  sparsity_lambda_l1=0.001, sparsity_lambda_group=0.01, sparsity_apply_to_spatial=True,
-                 sparsity_apply_to_temporal=True, seed=None, world_size=None):
+                 sparsity_apply_to_temporal=True, seed=None, world_size=None, dtype="f32"):
         self.model = model
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"unknown dtype '{dtype}'; use 'f32' or 'bf16'")
+        self.dtype = dtype
         if loss not in ("mse", "pinball"):
             raise ValueError(f"unknown loss '{loss}'; use 'mse' or 'pinball'")
         self.loss_kind = loss
@@ -164,6 +167,17 @@ class TrainStep:
         self.grad_clip = float(grad_clip or 0.0)
         self.step_count = 0
         self.max_batch = int(max_batch)
+        # BASELINE config C3 (dtype="bf16"): the Linear layers after the first take bf16 operands on the matrix
+        # cores.  Master weights, gradients, AdamW state and the EMA stay fp32 in the flat buffers; the bf16
+        # operand copies (each weight and its transpose) live in one buffer that the optimiser kernel rewrites
+        # from the values it has just stepped.
+        self._shadow_buf = None
+        self._shadow_regions = []
+        self._shadow_tables = {}
+        model.compute_dtype = dtype
+        model._bf16_engine = None
+        if dtype == "bf16":
+            self._install_bf16_copies()
         self.state = model._step_state(self.dev, force_dense=force_dense, training=True)
         assert self.state.w0_transposed
         self.uses_window = N.step_uses_window(self.state.basis, self.state.desc, self.state.flags)
@@ -268,6 +282,44 @@ class TrainStep:
         self._sched = None         # run_epoch under data parallelism: (dataset key, per-step per-rank batch sizes)
 
     # ------------------------------------------------------------------------------------
+    def _install_bf16_copies(self):
+        m = self.model
+        lins = m._linears()
+        by_name = {n: (o, k) for n, o, k in self.offsets}
+        names = {id(p): n for n, p in m.named_parameters()}
+        total = sum(2 * lins[l].weight.numel() for l in range(1, len(m.hidden_dims)))
+        self._shadow_buf = torch.empty(max(total, 8), device=self.dev, dtype=torch.bfloat16)
+        pairs, regions, pos = [None] * len(lins), [], 0
+        for l in range(1, len(m.hidden_dims)):
+            w = lins[l].weight
+            h, hp = w.shape
+            wb = self._shadow_buf[pos:pos + h * hp].view(h, hp)
+            wt = self._shadow_buf[pos + h * hp:pos + 2 * h * hp].view(hp, h)
+            pos += 2 * h * hp
+            pairs[l] = (wb, wt)
+            regions.append((by_name[names[id(w)]][0], h, hp, wb, wt))
+        self._shadow_regions = regions
+        m._bf16_engine = pairs
+        self.refresh_bf16()
+
+    def _shadow(self, base=0):
+        """stdadk_bf16_shadow table with offsets relative to flat[base:] (None in fp32 mode or without layers
+        after the first)."""
+        if not self._shadow_regions:
+            return None
+        key = int(base)
+        if key not in self._shadow_tables:
+            self._shadow_tables[key] = N.make_bf16_shadow([(o - key, h, hp, wb, wt)
+                                                           for o, h, hp, wb, wt in self._shadow_regions])
+        return self._shadow_tables[key]
+
+    def refresh_bf16(self):
+        """Re-round the bf16 operand copies from the fp32 master weights: needed after the parameters were
+        changed by anything but this engine's optimiser (load_state_dict, in-place edits); swap_in_ema calls it."""
+        sh = self._shadow(0)
+        if sh is not None:
+            N.bf16_shadow_refresh(self.flat, sh)
+
     def set_lr(self, lr):
         self.lr = float(lr)
         self.lr_dev.fill_(self.lr)
@@ -294,7 +346,8 @@ class TrainStep:
             if self._optim is None:
                 self._optim = N.make_optim(self.flat, self.grad, self.m, self.v, self.ema, self.lr, self.lr_dev,
                                            self.betas, self.eps, self.wd, self.step_dev, self.grad_clip,
-                                           self._sumsq512 if self.grad_clip > 0 else None, self.ema_decay)
+                                           self._sumsq512 if self.grad_clip > 0 else None, self.ema_decay,
+                                           shadow=self._shadow(0))
             N.train_step(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y,
                          idx if not prebinned else None, B, D.grad_scale(global_rows, Q), self.loss_sum, ws, flags,
                          self._optim, seed=self.seed, loss_desc=self._loss_desc(y.shape[1]),
@@ -369,7 +422,7 @@ class TrainStep:
             ema = self.ema
             g_mlp = N.make_adam_group(self.flat[ke:], self.grad[ke:], self.m[ke:], self.v[ke:],
                                       ema[ke:] if ema is not None else None, self.lr, self.lr_dev, self.grad_clip,
-                                      self.sumsq)
+                                      self.sumsq, shadow=self._shadow(ke))
             g_knot = N.make_adam_group(self.flat[:ke], self.grad[:ke], self.m[:ke], self.v[:ke],
                                        ema[:ke] if ema is not None else None, self.basis_lr, self.basis_lr_dev,
                                        self.basis_clip, self.sumsq_basis)
@@ -385,7 +438,8 @@ class TrainStep:
         ema = self.ema
         N.adamw_ema(self.flat[ke:], self.grad[ke:], self.m[ke:], self.v[ke:], ema[ke:] if ema is not None else None,
                     self.lr, self.betas, self.eps, self.wd, self.step_count + 1, max_norm=self.grad_clip,
-                    sumsq_parts=self.sumsq, ema_decay=self.ema_decay, lr_dev=self.lr_dev, step_dev=self.step_dev)
+                    sumsq_parts=self.sumsq, ema_decay=self.ema_decay, lr_dev=self.lr_dev, step_dev=self.step_dev,
+                    shadow=self._shadow(ke))
         if ke:
             N.adamw_ema(self.flat[:ke], self.grad[:ke], self.m[:ke], self.v[:ke], ema[:ke] if ema is not None else None,
                         self.basis_lr, self.betas, self.eps, self.wd, self.step_count + 1, max_norm=self.basis_clip,
@@ -608,6 +662,7 @@ class TrainStep:
         tmp = self.flat.clone()
         self.flat.copy_(self.ema)
         self.ema.copy_(tmp)
+        self.refresh_bf16()
         self.model._engine_version = getattr(self.model, "_engine_version", 0) + 1
 
 

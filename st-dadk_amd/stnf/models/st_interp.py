@@ -3,8 +3,12 @@
 Drop-in for the reference's stnf/models/st_interp.py on the fixed-knot MSE path: same class
 names, constructor signatures, attribute names, state_dict keys and error behaviour
 (reference st_interp.py:18-150, :549-596, :599-692, :885-919), but forward()/backward() run the
-hand-written HIP kernels of libstdadk.so (feature builder, fp32-MFMA MLP).  There is no CPU
-arithmetic path: tensors must live on a HIP device.
+hand-written HIP kernels of libstdadk.so (feature builder, fp32-MFMA MLP) whenever the tensors live on
+a HIP device.  Host tensors (the reference's shipped default is `device: cpu`,
+configs/config_st_interp.yaml:85) take a plain-torch statement of the same formulas further down
+(`_host_*`): it exists so that the reference's driver, tests and CPU-only tooling keep working against
+this package -- it is not the product's fast path, the fused engine (stnf.engine) has no host
+counterpart, and nothing here touches the repository's test infrastructure.
 
 Knot tables are generated on the host with the same torch calls the reference makes
 (torch.linspace + meshgrid 'ij'), so the buffers are bit-identical by construction; only integer
@@ -27,6 +31,28 @@ _DENSE0_MAX_D = 512        # TAIL_D0_MAX of csrc/tail.h
 
 def _round_up(a, b):
     return (a + b - 1) // b * b
+
+
+def _host_phi(coords, centers, bandwidths, basis):
+    """phi on host tensors with autograd: direct Euclidean distances (no matmul expansion: that form loses
+    half the digits near a knot), radius = distance / (bandwidth x calibration), then the basis
+    profile (reference :433-491).  coords (N,2) or (B,N,2)."""
+    cal = SpatialBasisEmbedding.CALIBRATION_FACTORS[basis]
+    rad = torch.cdist(coords, centers, compute_mode="donot_use_mm_for_euclid_dist") / (bandwidths * cal)
+    if basis == 'wendland':
+        rad = torch.clamp(rad, max=1.0)
+        gap = 1.0 - rad
+        gap3 = gap * gap * gap
+        return gap3 * gap3 * ((35.0 * rad + 18.0) * rad + 3.0) / 3.0
+    if basis == 'gaussian':
+        return torch.exp(-0.5 * rad * rad)
+    return torch.clamp(1.0 - rad, min=0.0)
+
+
+def _host_psi(t, centers, bandwidths):
+    """psi on host tensors: exp(-((t - c)/bw)^2 / 2) per temporal knot (reference :583-596)."""
+    u = (t.reshape(-1, 1) - centers.reshape(1, -1)) / bandwidths.reshape(1, -1)
+    return torch.exp(-0.5 * u * u)
 
 
 class _PhiFunction(torch.autograd.Function):
@@ -176,6 +202,9 @@ class SpatialBasisEmbedding(nn.Module):
         if coords.dim() == 3:       # the reference accepts (B,N,2); flatten the batch
             b, n, _ = coords.shape
             coords, squeeze = coords.reshape(b * n, 2), (b, n)
+        if not coords.is_cuda:
+            out = _host_phi(coords, self.centers, self.bandwidths, self.basis_function)
+            return out.view(*squeeze, self.k) if squeeze else out
         coords = coords.contiguous().float()
         if self.learnable and torch.is_grad_enabled() and (self.centers.requires_grad or self.log_bandwidths.requires_grad):
             # differentiable w.r.t. the knots, as the reference's module is (its forward is plain autograd ops)
@@ -217,6 +246,8 @@ class TemporalBasisEmbedding(nn.Module):
 
     def forward(self, t: torch.Tensor):
         """t (N,1) -> psi (N,k_time) via stdadk_rbf_build_f32 (reference :583-596)."""
+        if not t.is_cuda:
+            return _host_psi(t, self.centers, self.bandwidths)
         t = t.contiguous().float().view(-1)
         out = torch.empty(t.shape[0], self.k_time, device=t.device, dtype=torch.float32)
         N.rbf_build(None, t, None, None, None, 'wendland', self.centers, self.bandwidths, out)
@@ -300,7 +331,7 @@ class _SparsityFunction(torch.autograd.Function):
 
 class _StepState:
     """ABI descriptors for one forward/backward pair (keeps the tensors they point to alive)."""
-    __slots__ = ("basis", "desc", "params", "flags", "w0_transposed", "keep", "delta", "head")
+    __slots__ = ("basis", "desc", "params", "flags", "w0_transposed", "keep", "delta", "head", "bf16")
 
 
 class STInterpMLP(nn.Module):
@@ -359,6 +390,10 @@ class STInterpMLP(nn.Module):
             self.mlp = nn.Sequential(*layers)
             self.mlp_trunk = None
             self.delta_params = None
+        # "f32" (the reference's arithmetic) or "bf16" (BASELINE config C3: the Linear layers after the first take
+        # bf16 operands on the matrix cores, fp32 accumulation / LayerNorm / loss / master weights)
+        self.compute_dtype = "f32"
+        self._bf16_engine = None
         # diagnostics: True forces the materialising (dense) kernels even where the window path applies
         self.force_dense_path = False
         # diagnostics: True takes the window kernels wherever supported, also for small knot tables
@@ -389,7 +424,25 @@ class STInterpMLP(nn.Module):
         knots = [sb.centers, sb.log_bandwidths] if sb.learnable else []
         return knots + self._body_params() + (list(self.delta_params) if self._has_delta else [])
 
-    def _pack(self, flat_list):
+    def _bf16_copies(self, weights):
+        """bf16 operand copies of the hidden Linear layers after the first (BASELINE config C3): per Linear
+        index None or (W_bf16 (out,in), WT_bf16 (in,out)), rounded from `weights` (the fp32 Linear weights in
+        layer order) by stdadk_bf16_shadow_refresh.  An engine (stnf.engine.TrainStep) installs persistent
+        copies that its optimiser kernel keeps current; otherwise they are made afresh for the call."""
+        if self._bf16_engine is not None:
+            return self._bf16_engine
+        out = [None] * len(weights)
+        n_hidden = len(self.hidden_dims)
+        for l in range(1, n_hidden):
+            w = weights[l]
+            h, hp = w.shape
+            pair = (torch.empty(h, hp, device=w.device, dtype=torch.bfloat16),
+                    torch.empty(hp, h, device=w.device, dtype=torch.bfloat16))
+            N.bf16_shadow_refresh(w, N.make_bf16_shadow([(0, h, hp, pair[0], pair[1])]))
+            out[l] = pair
+        return out
+
+    def _pack(self, flat_list, bf16=None):
         """Tensors in _body_params() order (+ the derived [Wo, bo] under the delta head) -> ABI struct."""
         it = iter(flat_list)
         Ws, bs, gs, betas = [], [], [], []
@@ -400,7 +453,7 @@ class STInterpMLP(nn.Module):
                 gs.append(next(it)); betas.append(next(it))
         if self._has_delta:
             Ws.append(next(it)); bs.append(next(it))
-        return N.make_tensors(Ws, bs, gs if self.layernorm else None, betas if self.layernorm else None)
+        return N.make_tensors(Ws, bs, gs if self.layernorm else None, betas if self.layernorm else None, bf16=bf16)
 
     def _delta_matrix(self, tensors=None):
         """(Q, d+1) matrix of the delta vectors (or of `tensors`, e.g. their gradients): a strided
@@ -471,9 +524,15 @@ class STInterpMLP(nn.Module):
             st.keep = w0.t().contiguous()
             tensors[0] = st.keep
             flags |= N.FLAG_W0_T
+        st.bf16 = None
+        if self.compute_dtype == "bf16":
+            # layers after the first on the bf16 matrix cores; fp32 master weights, bf16 operand copies
+            flags |= N.FLAG_BF16
+            lin_w = [tensors[i] for i, p in enumerate(self._body_params()) if p.dim() == 2]
+            st.bf16 = self._bf16_copies(lin_w)
         st.flags = flags
         st.w0_transposed = bool(flags & N.FLAG_W0_T)
-        st.params = self._pack(tensors)
+        st.params = self._pack(tensors, bf16=st.bf16)
         return st
 
     def build_features(self, X, coords, t, out=None):
@@ -533,11 +592,27 @@ class STInterpMLP(nn.Module):
         return {'spatial_penalty': pens[0], 'temporal_penalty': pens[1],
                 'total_penalty': pens[0] + pens[1]}
 
+    def _host_forward(self, X, coords, t):
+        """The model on host tensors, plain torch ops with autograd (`device: cpu`): [X | phi | psi] through the
+        nn.Sequential stack; under the delta head the Q outputs are the trunk's features against the running sums
+        of the delta vectors (intercept in slot 0), reference :849-877."""
+        if next(self.parameters()).is_cuda:
+            raise RuntimeError("the model's parameters are on a HIP device but the inputs are host tensors; move "
+                               "the inputs (config `device: cuda`) or the model")
+        cols = [self.spatial_basis(coords), self.temporal_basis(t)]
+        if self.p > 0 and X is not None and X.numel() > 0:
+            cols.insert(0, X)
+        feats = torch.cat(cols, dim=-1)
+        if not self._has_delta:
+            return self.mlp(feats)
+        hidden = self.mlp_trunk(feats)
+        beta = torch.cumsum(torch.stack(list(self.delta_params)), dim=0)          # (Q, d+1): beta_k = sum_{l<=k} delta_l
+        return hidden @ beta[:, 1:].t() + beta[:, 0]
+
     def forward(self, X: torch.Tensor, coords: torch.Tensor, t: torch.Tensor):
         """X (B,p), coords (B,2), t (B,1) -> y_pred (B,Q)   (reference :827-882)."""
         if not coords.is_cuda:
-            raise RuntimeError("stnf (MI355X build): forward() needs tensors on a HIP device "
-                               "(config `device: cuda`); there is no CPU path")
+            return self._host_forward(X, coords, t)
         coords = coords.contiguous().float()
         t = t.contiguous().float().view(-1)
         Xc = None

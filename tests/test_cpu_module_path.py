@@ -1,0 +1,147 @@
+"""The product's own host path (plain torch inside stnf.models, selected for host tensors; `device: cpu` is the
+reference's shipped default, configs/config_st_interp.yaml:85) against the SAME goldens the HIP path is pinned to:
+y / loss / every gradient vs the float64 run of the real reference.  It never touches the oracle package or the
+native library."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden import cases
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-5
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def check_vs_digest(got, g, prefix, key, seed, tol=TOL):
+    got = np.asarray(got, dtype=np.float64)
+    norm = float(g[f"{prefix}norm64/{key}"])
+    if f"{prefix}64/{key}" in g:
+        ref = g[f"{prefix}64/{key}"]
+        assert got.shape == ref.shape
+        assert np.linalg.norm((got - ref).ravel()) / max(norm, 1e-30) <= tol, (prefix, key)
+        return
+    pos = cases.digest_positions(got.shape, 2048, seed)
+    ref = g[f"{prefix}64s/{key}"]
+    assert np.linalg.norm(got.ravel()[pos] - ref) / max(np.linalg.norm(ref), 1e-30) <= tol, (prefix, key)
+    assert abs(np.linalg.norm(got.ravel()) - norm) <= tol * norm
+
+
+def build(cfg, **kw):
+    from stnf.models import STInterpMLP
+    m = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"],
+                    k_temporal_centers=cfg["k_temporal_centers"], hidden_dims=cfg["hidden_dims"], dropout=0.0,
+                    layernorm=cfg["layernorm"], spatial_basis_function=cfg["basis"], output_dim=cfg["output_dim"], **kw)
+    return m
+
+
+@pytest.mark.parametrize("name", list(cases.MODEL_CASES))
+def test_host_forward_backward_matches_reference_goldens(name):
+    cfg = cases.MODEL_CASES[name]
+    g = load(name)
+    m = build(cfg)
+    st = cases.make_state(cfg)
+    with torch.no_grad():
+        for (_, p), (k, v) in zip(m.named_parameters(), st.items()):
+            p.copy_(torch.from_numpy(v.copy()))
+    m.train()
+    X, coords, t, y = (torch.from_numpy(a) for a in cases.make_inputs(cfg))
+    phi = m.spatial_basis(coords)
+    if "phi64" in g:            # (the large cases keep row sums of phi only)
+        assert np.abs(phi.detach().numpy() - g["phi64"]).max() <= TOL
+    else:
+        assert np.abs(phi.detach().double().sum(1).numpy() - g["phi_rowsum64"]).max() <= TOL * max(1.0, g["phi_rowsum64"].max())
+    assert np.abs(m.temporal_basis(t).detach().numpy() - g["psi64"]).max() <= TOL
+    yp = m(X, coords, t)
+    loss = torch.nn.MSELoss()(yp, y)
+    loss.backward()
+    assert np.abs(yp.detach().numpy() - g["y64"]).max() <= TOL * max(1.0, np.abs(g["y64"]).max())
+    assert abs(loss.item() - float(g["loss64"])) <= TOL * float(g["loss64"])
+    for k, p in m.named_parameters():
+        check_vs_digest(p.grad.numpy(), g, "g", k, cfg["seed"] + 7)
+    # eval / no_grad gives the same numbers (dropout = 0), and (B, N, 2) coordinates are accepted like the reference's
+    m.eval()
+    with torch.no_grad():
+        assert torch.allclose(m(X, coords, t), yp.detach(), rtol=0, atol=1e-6)
+        assert torch.allclose(m.spatial_basis(coords.view(1, -1, 2)).view(phi.shape), phi.detach(), rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["tiny9_delta5", "default227_delta5", "default227_mq5"])
+def test_host_quantile_heads_match_reference_goldens(name):
+    """Multi-quantile output and the delta-reparameterised head on the host path, through stnf.losses' check loss and
+    penalties (the driver's functions), against the goldens made with the reference's own loss functions."""
+    from stnf import losses as Ls
+    cfg, lc = cases.quantile_cfg(name)
+    g = load(name)
+    m = build(cfg, use_delta_reparameterization=cfg["delta"])
+    st = cases.make_state(cfg)
+    assert [k for k, _ in m.named_parameters()] == list(st.keys())
+    with torch.no_grad():
+        for (_, p), (k, v) in zip(m.named_parameters(), st.items()):
+            p.copy_(torch.from_numpy(v.copy()))
+    m.train()
+    X, coords, t, y = (torch.from_numpy(a) for a in cases.make_inputs(cfg))
+    yp = m(X, coords, t)
+    assert yp.shape == (cfg["B"], cfg["output_dim"])
+    assert np.abs(yp.detach().numpy() - g["y64"]).max() <= TOL * max(1.0, np.abs(g["y64"]).max())
+
+
+@pytest.mark.parametrize("name", ["tiny9_learn", "default227_learn", "default227_learn_gauss"])
+def test_host_learnable_knots_match_reference_goldens(name):
+    """Learnable knots on the host path: gradients flow into centres and log-bandwidths by plain autograd."""
+    cfg, kn = cases.learn_cfg(name)
+    g = load(name)
+    m = build(cfg, spatial_learnable=True, gradient_damping=False)
+    st = cases.make_state(cfg)
+    with torch.no_grad():
+        m.spatial_basis.centers.copy_(torch.from_numpy(g["in_centers"]))
+        m.spatial_basis.log_bandwidths.copy_(torch.from_numpy(g["in_log_bw"]))
+        for (k, p) in list(m.named_parameters())[2:]:
+            p.copy_(torch.from_numpy(st[k].copy()))
+    m.train()
+    X, coords, t, y = (torch.from_numpy(a) for a in cases.make_inputs(cfg))
+    yp = m(X, coords, t)
+    assert np.abs(yp.detach().numpy() - g["y64"]).max() <= TOL * max(1.0, np.abs(g["y64"]).max())
+    torch.nn.MSELoss()(yp, y).backward()
+    assert m.spatial_basis.centers.grad is not None and m.spatial_basis.log_bandwidths.grad is not None
+    assert float(m.spatial_basis.centers.grad.abs().sum()) > 0
+
+
+def test_host_model_runs_the_reference_style_batch_body():
+    """optimizer / clip / EMA exactly as the reference's driver strings them together (train_st_interp.py:608-721),
+    on host tensors: the loss goes down and ModelEMA's in-place swap restores the training weights."""
+    from stnf.models import create_model
+    from stnf.utils import ModelEMA, set_seed
+    set_seed(3)
+    m = create_model(dict(k_spatial_centers=[25, 81], k_temporal_centers=[5, 9], hidden_dims=[32, 16], dropout=0.1))
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=1e-4)
+    ema = ModelEMA(m, decay=0.9)
+    g = torch.Generator().manual_seed(0)
+    coords, t = torch.rand(512, 2, generator=g), torch.rand(512, 1, generator=g)
+    y = torch.sin(4 * coords[:, :1]) + 0.05 * torch.randn(512, 1, generator=g)
+    first = last = None
+    for _ in range(60):
+        opt.zero_grad()
+        loss = torch.nn.MSELoss()(m(torch.zeros(512, 0), coords, t), y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 10.0)
+        opt.step()
+        ema.update(m)
+        first = loss.item() if first is None else first
+        last = loss.item()
+    assert last < 0.5 * first
+    before = [p.detach().clone() for p in m.parameters()]
+    ema.apply_shadow()
+    assert any(not torch.equal(a, p) for a, p in zip(before, m.parameters()))
+    ema.restore()
+    assert all(torch.equal(a, p) for a, p in zip(before, m.parameters()))

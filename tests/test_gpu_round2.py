@@ -107,10 +107,13 @@ def test_c4_b4096_window_all_gradients_vs_oracle():
         e = T.rel_l2(p.grad.cpu().numpy(), go[k])
         worst = max(worst, e)
         assert e <= TOL, (k, e)
-    # knots no observation reaches have an exactly zero row in both
+    # knots no observation reaches have an exactly zero column of dW0 in both
     g0 = m._body[0].weight.grad.cpu().numpy()
-    k0 = next(iter(go))
-    assert np.array_equal(np.abs(g0).sum(0) == 0, np.abs(go[k0]).sum(0) == 0)
+    assert g0.shape == go["mlp.0.weight"].shape == (256, 49798)
+    zk, zo = np.abs(g0).sum(0) == 0, np.abs(go["mlp.0.weight"]).sum(0) == 0
+    assert np.all(zk[zo])                                          # oracle zero => kernel zero
+    # (the fp32 kernel may flush a (1-r)^6 of ~1e-40 the float64 oracle still carries: negligible columns only)
+    assert np.abs(go["mlp.0.weight"][:, zk & ~zo]).max(initial=0.0) <= 1e-25
     print(f"C4 B=4096 worst gradient rel-L2 vs oracle: {worst:.2e}")
 
 
@@ -409,8 +412,7 @@ def test_spatial_embedding_is_differentiable_wrt_learnable_knots(basis):
     c = sb.centers.detach().cpu().double().requires_grad_(True)
     lb = sb.log_bandwidths.detach().cpu().double().requires_grad_(True)
     x = coords.cpu().double()
-    diff = x[:, None, :] - c[None, :, :]
-    dist = torch.sqrt((diff ** 2).sum(-1))
+    dist = torch.cdist(x, c, compute_mode="donot_use_mm_for_euclid_dist")    # zero gradient at zero distance
     cal = SpatialBasisEmbedding.CALIBRATION_FACTORS[basis]
     r = dist / (torch.exp(lb)[None, :] * cal)
     if basis == "wendland":

@@ -34,7 +34,8 @@ def test_abi_struct_layout_matches_header():
     from stnf import _native as N
     # stdadk_mlp_desc: int32 n_hidden, in_dim, hidden[8], out_dim, layernorm; float ln_eps, dropout_p
     assert ctypes.sizeof(N.MlpDesc) == 4 * (2 + 8 + 2 + 2)
-    assert ctypes.sizeof(N.MlpTensors) == 8 * (9 + 9 + 8 + 8)
+    assert ctypes.sizeof(N.MlpTensors) == 8 * (9 + 9 + 8 + 8 + 9 + 9)      # + W_bf16, WT_bf16
+    assert ctypes.sizeof(N.BF16Region) == 8 + 4 + 4 + 8 + 8 and ctypes.sizeof(N.BF16Shadow) == 8 + 8 * 32
     # stdadk_basis_desc: 3 + 8 int32 (padded to 48), 2 int64, 4 pointers
     assert ctypes.sizeof(N.BasisDesc) == 48 + 16 + 32
     d = N.make_desc(297, [256, 256, 128], 1, True, 0.1)
@@ -51,13 +52,18 @@ def test_missing_library_fails_loudly(monkeypatch):
         N.lib()
 
 
-def test_no_cpu_path():
+def test_native_library_refuses_host_tensors():
+    """The HIP library and the fused engine have no host fallback: host tensors raise (the module's own plain-torch
+    host path, tested in test_cpu_module_path.py, is a separate, explicit implementation)."""
+    from stnf import _native as N
+    from stnf.engine import TrainStep
     from stnf.models import STInterpMLP
     m = STInterpMLP(k_spatial_centers=[9], k_temporal_centers=[5], hidden_dims=[32, 16], dropout=0.0)
     with pytest.raises(RuntimeError, match="HIP device"):
-        m(torch.zeros(4, 0), torch.rand(4, 2), torch.rand(4, 1))
-    with pytest.raises(RuntimeError):
-        m.spatial_basis(torch.rand(4, 2))
+        TrainStep(m)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        N.rbf_build(torch.rand(4, 2), None, None, m.spatial_basis.centers, m.spatial_basis.bandwidths, "wendland",
+                    None, None, torch.empty(4, 9))
 
 
 def test_product_never_imports_the_oracle():
@@ -243,10 +249,13 @@ def test_n3_host_surface():
     from stnf.models import STInterpMLP
     # stdadk_loss_desc: int32 kind, y_cols; float tau[8], nc_weight; int32 nc_power
     assert ctypes.sizeof(N.LossDesc) == 4 * (2 + 8 + 2)
-    # stdadk_adam_group: 5 pointers, int64 n, float lr (+pad), pointer, float max_norm (+pad), pointer, int32 (+pad)
-    assert ctypes.sizeof(N.AdamGroup) == 88 and N.AdamGroup.lr_dev.offset == 56 and N.AdamGroup.n_parts.offset == 80
+    # stdadk_adam_group: 5 pointers, int64 n, float lr (+pad), pointer, float max_norm (+pad), pointer, int32 (+pad),
+    # pointer to the bf16 shadow table
+    assert ctypes.sizeof(N.AdamGroup) == 96 and N.AdamGroup.lr_dev.offset == 56 and N.AdamGroup.n_parts.offset == 80
+    assert N.AdamGroup.shadow.offset == 88
     # stdadk_optim_desc: 5 pointers, int64, float (+pad), pointer, 4 floats, pointer, float (+pad), pointer, float (+pad)
-    assert ctypes.sizeof(N.OptimDesc) == 112 and N.OptimDesc.step_dev.offset == 80 and N.OptimDesc.sumsq_parts.offset == 96
+    assert ctypes.sizeof(N.OptimDesc) == 120 and N.OptimDesc.step_dev.offset == 80 and N.OptimDesc.sumsq_parts.offset == 96
+    assert N.OptimDesc.shadow.offset == 112
     assert ctypes.sizeof(N.SparsityDesc) == 20 and N.SparsityDesc.apply_spatial.offset == 12
     # stdadk_knot_train: pointer, int32, 6 floats (+pad to 8)
     assert ctypes.sizeof(N.KnotTrain) == 40
