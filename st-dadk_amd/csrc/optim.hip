@@ -3,6 +3,8 @@
 // ema.update), torch.optim.AdamW's update rule and stnf/utils/ema.py:52-66.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace stdadk {
 
 // parts[blockIdx.x] = sum of squares of this block's slice (every one of the SUMSQ_PARTS entries is
@@ -282,8 +284,12 @@ extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v
   STDADK_REQUIRE(a.sh.n == 0 || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                                   reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(ema)) & 15) == 0,
                  STDADK_E_ALIGN, "adamw: bf16 shadows need 16-byte aligned buffers");
+  // grid: at most 6 workgroups per CU = ONE resident round of the chip (72 VGPRs: 7 fit), each thread walking
+  // its float4 groups with a grid stride -- a second, partly filled round of one-group threads cost 3 us of the
+  // 20 (MI355X, 2.76 M parameters, tools/sweep_knobs.sh: 2 695 blocks 20.6 us, 1 536 blocks 17.6 us = 5.6 TB/s)
   int64_t blocks = ceil_div(n, 256 * 4);
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 1536) blocks = 1536;
+  { const char *e = getenv("STDADK_ADAMW_BLOCKS"); if (e && atoi(e) > 0) blocks = atoi(e); }   // measurement aid
   STDADK_LAUNCH(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   STDADK_CHECK_LAUNCH("adamw_ema");
   return 0;
@@ -328,8 +334,8 @@ extern "C" int stdadk_adamw_ema2_f32(const stdadk_adam_group *g0, const stdadk_a
   rc = fill_group(a1, g1, beta1, beta2, eps, weight_decay, step, step_dev, grad_mul, ema_decay);
   if (rc) return rc;
   int64_t nb0 = ceil_div(a0.n, 256 * 4), nb1 = ceil_div(a1.n, 256 * 4);
-  if (nb0 > 4096) nb0 = 4096;
-  if (nb1 > 4096) nb1 = 4096;
+  if (nb0 > 1536) nb0 = 1536;        // one resident round of the chip (see stdadk_adamw_ema_f32)
+  if (nb1 > 1536) nb1 = 1536;
   STDADK_LAUNCH(adamw_ema2_kernel, dim3((unsigned)(nb0 + nb1)), dim3(256), 0, (hipStream_t)stream, a0, a1, (int)nb0);
   STDADK_CHECK_LAUNCH("adamw_ema2");
   return 0;

@@ -11,6 +11,8 @@
 // 4 KiB contiguous per row.  Algorithmic bytes: 12 B read + 4*(p+Ks+Kt) B written per observation.
 #include "basis.h"
 
+#include <stdlib.h>
+
 namespace stdadk {
 
 constexpr int TILE_C = 1024;
@@ -126,10 +128,16 @@ static void launch_rbf(const float *coords, const float *t, const float *X, int6
                        const float *t_centers, const float *t_bw, int64_t Kt, float *out,
                        int64_t ld_out, hipStream_t st) {
   const int64_t n_tiles = ceil_div(ld_out, TILE_C);
-  // rows per workgroup: enough workgroups to fill 256 CUs x 8, at least 16 rows each; ONE launch
-  // covers every column tile so the few edge tiles run beside the spatial ones
-  int rows = 64;
-  while (rows > 16 && ceil_div(B, rows) * n_tiles < 2048) rows >>= 1;
+  // ONE launch covers every column tile so the few edge tiles run beside the spatial ones.  Rows per workgroup:
+  // 4.  The grid's x index (column tile) runs fastest, so the workgroups in flight at any time cover a dense
+  // band of consecutive rows of the output: with 4 rows each that band is a few MB that the memory controller
+  // sees as long sequential write bursts; with 64 rows per workgroup every workgroup is its own 4-KiB-per-42-KiB
+  // strided stream (~200 of them) and the DRAM pages thrash once the output no longer fits the 256 MiB
+  // Infinity Cache (MI355X, tools/bench_rbf_rows.py: C2 x 16 384 rows = 680 MB 4.94 -> 5.69 TB/s, C4 x 4 096
+  // = 816 MB 4.55 -> 5.24, C4 x 16 384 = 3.3 GB 5.21 -> 6.14; 1-2 rows lose again to the per-workgroup
+  // knot-table loads).  STDADK_RBF_ROWS overrides (measurement aid).
+  int rows = 4;
+  { const char *e = getenv("STDADK_RBF_ROWS"); if (e && atoi(e) > 0) rows = atoi(e); }
   while (ceil_div(B, rows) > 65535) rows <<= 1;      // gridDim.y limit
   dim3 grid((unsigned)n_tiles, (unsigned)ceil_div(B, rows));
   STDADK_LAUNCH((rbf_build_kernel<VEC, BASIS>), grid, dim3(RB_THREADS), 0, st, coords, t, X, B, p, s_centers,

@@ -151,10 +151,15 @@ __global__ void zero_ints_kernel(int *__restrict__ p, int n) {
   if (i < n) p[i] = 0;
 }
 
-// Whole binning in ONE workgroup for small batches (B <= SMALL_B, G <= SMALL_G): histogram, scan,
-// scatter and in-cell ordering with the counters and the unordered permutation in LDS.  Same
-// outputs, bit for bit, as the multi-kernel path.
-constexpr int SMALL_B = 8192, SMALL_G = 64;
+// Whole binning in ONE launch for small batches (B <= SMALL_B, G <= SMALL_G): histogram, scan, scatter and
+// in-cell ordering with the counters and the unordered permutation in LDS.  Same outputs, bit for bit, as
+// the multi-kernel path.  SMALL_WG workgroups share the work without talking to each other: every one builds
+// the complete histogram / scan / unordered permutation in its OWN LDS (8 192 keys are 64 KB of L2 reads), then
+// orders only the cells that reach into its slice of the sorted positions and emits only that slice (the
+// in-cell order is by original index, so the workgroups' different atomic arrival orders do not show).  What is
+// split -- the ordering loops and the dependent row gathers of the emission -- is the longer half of the
+// single-workgroup kernel's latency chain (MI355X, B = 4096: 21 us with one workgroup).
+constexpr int SMALL_B = 8192, SMALL_G = 64, SMALL_WG = 8;
 __global__ __launch_bounds__(1024) void bin_small_kernel(const int64_t *__restrict__ idx,
                                                          const float *__restrict__ coords,
                                                          const float *__restrict__ t,
@@ -172,6 +177,9 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const int64_t *__restri
   const int tid = threadIdx.x;
   const int ncell = G * G;
   constexpr int PER_T = SMALL_B / 1024;        // observations per thread
+  // this workgroup's slice [lo, hi) of the batch positions (keys) and of the sorted positions (everything else)
+  const int per_wg = ((B + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63;
+  const int lo = min((int)blockIdx.x * per_wg, B), hi = min(lo + per_wg, B);
   for (int c = tid; c < ncell; c += 1024) hist[c] = 0;
   __syncthreads();
   int kk[PER_T];
@@ -185,7 +193,10 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const int64_t *__restri
 #pragma unroll
   for (int i = 0; i < PER_T; ++i) {
     const int b = tid + 1024 * i;
-    if (b < B) { keys[b] = kk[i]; atomicAdd(&hist[kk[i]], 1); }
+    if (b < B) {
+      if (b >= lo && b < hi) keys[b] = kk[i];
+      atomicAdd(&hist[kk[i]], 1);
+    }
   }
   __syncthreads();
   // exclusive scan: thread tid owns cells [tid*per, tid*per+per); wave-level shuffles, two barriers
@@ -216,11 +227,14 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const int64_t *__restri
   for (int i = i0; i < i1; ++i) {
     const int cnt = hist[i];
     start[i] = run;
-    cell_start[i] = run;
+    if (blockIdx.x == 0) cell_start[i] = run;
     hist[i] = run;            // cursor for the scatter
     run += cnt;
   }
-  if (tid == 1023) { start[ncell] = part[31]; cell_start[ncell] = part[31]; }
+  if (tid == 1023) {
+    start[ncell] = part[31];
+    if (blockIdx.x == 0) cell_start[ncell] = part[31];
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < PER_T; ++i) {
@@ -228,9 +242,10 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const int64_t *__restri
     if (b < B) ptmp[atomicAdd(&hist[kk[i]], 1)] = b;
   }
   __syncthreads();
-  // order every cell by original index (rank by counting): LDS only
+  // order every cell that reaches into [lo, hi) by original index (rank by counting): LDS only
   for (int c = tid; c < ncell; c += 1024) {
     const int s0 = start[c], s1 = start[c + 1];
+    if (s1 <= lo || s0 >= hi) continue;
     for (int i = s0; i < s1; ++i) {
       const int b = ptmp[i];
       int rank = 0;
@@ -242,12 +257,13 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const int64_t *__restri
   // emit the sorted arrays: one position per thread and pass, independent loads
 #pragma unroll
   for (int i = 0; i < PER_T; ++i) {
-    const int pos = tid + 1024 * i;
-    const int b = pfin[min(pos, B - 1)];
+    const int pos = lo + tid + 1024 * i;
+    if (lo + 1024 * i >= hi) break;              // workgroup-uniform
+    const int b = pfin[min(pos, hi - 1)];
     const int64_t r = idx ? idx[b] : b;
     const float cx = coords[2 * r], cy = coords[2 * r + 1];
     const float tv = t ? t[r] : 0.f;
-    if (pos < B) {
+    if (pos < hi) {
       perm[pos] = b;
       xs[pos] = cx;
       ys[pos] = cy;
@@ -264,7 +280,8 @@ int bin_obs(const float *coords, const float *t, const float *y, int Q, const fl
             int G, const BinBuffers &bb, hipStream_t st, const int64_t *idx, bool many_small) {
   const int ncell = G * G;
   if (B <= SMALL_B && G <= SMALL_G && !many_small) {
-    STDADK_LAUNCH(bin_small_kernel, dim3(1), dim3(1024), 0, st, idx, coords, t, y, Q, X, p, B, G, bb.keys,
+    // (a few hundred rows are not worth splitting: one workgroup)
+    STDADK_LAUNCH(bin_small_kernel, dim3(B >= 1024 ? SMALL_WG : 1), dim3(1024), 0, st, idx, coords, t, y, Q, X, p, B, G, bb.keys,
                   bb.cell_start, bb.perm, bb.xs, bb.ys, bb.ts, y ? bb.y_s : (float *)nullptr,
                   (X && p > 0) ? bb.X_s : (float *)nullptr);
     STDADK_CHECK_LAUNCH("bin_obs");
