@@ -86,9 +86,10 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel, workload, B, dtype):
+def pmc_traffic(kernel, workload, B, dtype, grid_threads=None):
     """(bytes per launch, source) from the committed rocprofv3 PMC summary, or (None, reason): the figure is only
-    quoted for the kernel, workload, batch, dtype AND kernel sources it was measured on."""
+    quoted for the kernel, workload, batch, dtype AND kernel sources it was measured on.  `grid_threads`: for a
+    kernel the profiled run launches at several sizes, the entry of that grid size."""
     f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(f):
         return None, "no profiles/pmc_traffic.json"
@@ -103,6 +104,10 @@ def pmc_traffic(kernel, workload, B, dtype):
             return None, (f"stale: profiles/pmc_traffic.json was measured at {k}={src.get(k)!r}, this run has {v!r}; "
                           f"re-take the FETCH_SIZE / WRITE_SIZE passes (profiles/README.md)")
     short = kernel.replace("(stdadk::", "").replace("(", "").replace(")", "").split("<")[0]
+    if grid_threads is not None and f"{short}@{grid_threads}" in tj.get("kernels", {}):
+        short = f"{short}@{grid_threads}"
+    elif grid_threads is not None and any(k.startswith(short + "@") for k in tj.get("kernels", {})):
+        return None, f"{short}: no PMC entry for a grid of {grid_threads} threads"
     val = tj.get("kernels", {}).get(short)
     if val is None:
         return None, f"kernel {short} not in profiles/pmc_traffic.json"
@@ -421,7 +426,11 @@ def main():
                                                 feats), 50)
         rbf_bytes = B * (12 + 4 * D)                         # 12 B read + 4*D written / obs
         rbf_gbs = rbf_bytes / t_rbf / 1e9
-        rbf_traffic, rbf_traffic_src = pmc_traffic("rbf_build_kernel", args.workload, B, args.dtype)
+        ldf = (D + 31) // 32 * 32
+
+        def rbf_grid(rows):          # threads of one launch: column tiles of 1024 x 4 rows per workgroup x 256 threads
+            return -(-ldf // 1024) * -(-rows // 4) * 256
+        rbf_traffic, rbf_traffic_src = pmc_traffic("rbf_build_kernel", args.workload, B, args.dtype, rbf_grid(B))
         del feats
         # the same builder on a footprint well past the 256 MiB Infinity Cache (FETCH/WRITE_SIZE and a short
         # timed loop both see cache hits below it): rows so that the written features are >= 640 MB
@@ -435,8 +444,10 @@ def main():
         big_bytes = B_big * (12 + 4 * D)
         rbf_big = {"bound": "hbm", "achieved": big_bytes / t_big / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": big_bytes / t_big / 1e9 / HBM_PEAK_GBS, "rows": B_big, "bytes_per_launch": big_bytes,
-                   "avg_launch_us": t_big * 1e6, "traffic": None,
+                   "avg_launch_us": t_big * 1e6,
                    "note": "footprint past the 256 MiB Infinity Cache: every byte of the write stream reaches HBM"}
+        rbf_big["traffic"], rbf_big["traffic_source"] = pmc_traffic("rbf_build_kernel", args.workload, B, args.dtype,
+                                                                    rbf_grid(B_big))
         del feats_big, cb, tb_
         Q = model.output_dim
         floors = step_floors(B, H, Kt, Q, P_flat, nnz / B)

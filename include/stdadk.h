@@ -276,6 +276,14 @@ typedef struct stdadk_basis_desc {
                               * fp32 loss, fp32 master weights / gradients / optimiser state.  phi and psi are
                               * evaluated in fp32 and layer 0 stays fp32 on both paths.  Needs the fused tail
                               * kernels (hidden widths multiples of 16 up to 256); STDADK_E_ARG otherwise */
+#define STDADK_FLAG_SCATTERED 64 /* the spatial knots are NOT a uniform grid (gmm / random_site initialisers,
+                              * st_interp.py:187-343; learnable or fixed): basis->n_levels levels whose SIZES are
+                              * basis->side[l] (knot COUNT of level l, any positions; sum = Ks).  The window path
+                              * then bins the knots of every level into a 32 x 32 cell grid each step and an
+                              * observation gathers the knots of the cells within the level's largest support
+                              * radius of its own (same sums as the materialising path, zeros skipped).  Worth it
+                              * when the supports are small against the domain; the caller decides (the Python
+                              * face: expected candidates <= 35 % of the knots)                                  */
 #define STDADK_FLAG_WINDOW 8 /* take the window path whenever it is supported, even for small knot
                               * tables (default: tables under 1024 knots run the materialising
                               * path, which is faster there: a coarse level's few knots each own a

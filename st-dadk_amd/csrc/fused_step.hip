@@ -77,10 +77,10 @@ int l1_tail_launch(const L1FwdArgs &l_in, int basis, bool ln, const TailFwdArgs 
                    "l1_tail: STDADK_FLAG_BF16 needs params->WT_bf16 of every layer after the first");
 #define GO2(CPL_, BF_)                                                                                        \
   (basis == STDADK_BASIS_WENDLAND                                                                             \
-       ? (ln ? (l.halo ? launch<CPL_, true, 0, true, BF_>(l, f, b, st) : launch<CPL_, true, 0, false, BF_>(l, f, b, st)) \
-             : (l.halo ? launch<CPL_, false, 0, true, BF_>(l, f, b, st) : launch<CPL_, false, 0, false, BF_>(l, f, b, st))) \
-       : (ln ? (l.halo ? launch<CPL_, true, 2, true, BF_>(l, f, b, st) : launch<CPL_, true, 2, false, BF_>(l, f, b, st)) \
-             : (l.halo ? launch<CPL_, false, 2, true, BF_>(l, f, b, st) : launch<CPL_, false, 2, false, BF_>(l, f, b, st))))
+       ? (ln ? ((l.halo || l.kperm) ? launch<CPL_, true, 0, true, BF_>(l, f, b, st) : launch<CPL_, true, 0, false, BF_>(l, f, b, st)) \
+             : ((l.halo || l.kperm) ? launch<CPL_, false, 0, true, BF_>(l, f, b, st) : launch<CPL_, false, 0, false, BF_>(l, f, b, st))) \
+       : (ln ? ((l.halo || l.kperm) ? launch<CPL_, true, 2, true, BF_>(l, f, b, st) : launch<CPL_, true, 2, false, BF_>(l, f, b, st)) \
+             : ((l.halo || l.kperm) ? launch<CPL_, false, 2, true, BF_>(l, f, b, st) : launch<CPL_, false, 2, false, BF_>(l, f, b, st))))
 #define GO(CPL_) (f.bf16 ? GO2(CPL_, true) : GO2(CPL_, false))
   if (l.H == 256) return GO(4);
   return GO(2);

@@ -116,6 +116,71 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
       int n = 0;
       const int l1 = min(l0 + LSTEP, a.g.n_levels);
       for (int l = l0; FREE && l < l1; ++l) {
+        // a candidate's value into the per-wave list (non-zeros compacted by ballot + popcount; a full list is
+        // consumed, zero-padded to 8, and started over)
+        auto push = [&](float phi, int k) {
+          const uint64_t mask = __ballot(phi != 0.f);
+          const int m = __popcll(mask);
+          if (n + m > LIST - 8) {
+            const int npad = (n + 7) & ~7;
+            if (lane < npad - n) { my_phi[n + lane] = 0.f; my_k[n + lane] = 0; }
+            __builtin_amdgcn_wave_barrier();
+            consume(npad);
+            __builtin_amdgcn_wave_barrier();
+            n = 0;
+          }
+          if (phi != 0.f) {
+            const int pos = n + __popcll(mask & below);
+            my_phi[pos] = phi;
+            my_k[pos] = a.g.p + k;
+          }
+          n += m;
+        };
+        if (a.kperm) {
+          // scattered knots: the level's knots were binned into a Gk x Gk cell grid (knot_bins); the candidates are
+          // the knots of the cells within ceil(reach Gk) + 1 of the observation's cell -- every knot whose support
+          // can reach it (a knot outside the domain sits in a border cell: never farther in cells than in fact).
+          // A row of cells is one contiguous run of kperm: the rows' runs are walked as ONE flat list, 64 candidates
+          // per pass (the same segment walk as the per-knot gather of dW0^T).
+          const int Gk = a.Gk;
+          const float rc = a.reach[l];
+          const int rad = (rc < 4.0f) ? (int)ceilf(rc * (float)Gk) + 1 : Gk;        // NaN / huge: the whole level
+          const int ocx = floor_clamp(x * (float)Gk, Gk), ocy = floor_clamp(y * (float)Gk, Gk);
+          const int cx_lo = max(ocx - rad, 0), cx_hi = min(ocx + rad, Gk - 1);
+          const int cy_lo = max(ocy - rad, 0), cy_hi = min(ocy + rad, Gk - 1);
+          const int *cs = a.kcs + (size_t)l * (Gk * Gk + 1);
+          const int cxl = cx_lo + lane;                                              // Gk <= 64: one lane per cell row
+          int seg0 = 0, seg1 = 0;
+          if (cxl <= cx_hi) { seg0 = cs[cxl * Gk + cy_lo]; seg1 = cs[cxl * Gk + cy_hi + 1]; }
+          int incl = seg1 - seg0;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+          }
+          const int total = __shfl(incl, 63, 64);
+          for (int f0 = 0; f0 < total; f0 += 64) {
+            const int f = f0 + lane;
+            int lo = 0;
+#pragma unroll
+            for (int st = 32; st > 0; st >>= 1) {
+              const int probe = __shfl(incl, lo + st - 1, 64);
+              if (probe <= f) lo += st;
+            }
+            const int jl = lo < 63 ? lo : 63;
+            const int pin = __shfl(incl, jl, 64);
+            const int pl = __shfl(seg1 - seg0, jl, 64);
+            const int ps0 = __shfl(seg0, jl, 64);
+            float phi = 0.f;
+            int k = 0;
+            if (f < total) {
+              k = a.kperm[ps0 + (f - (pin - pl))];
+              phi = phi_eval<BASIS>(x, y, a.g.centers[2 * k], a.g.centers[2 * k + 1], knot_scale(a.g.bw[k], a.g.cal));
+            }
+            push(phi, k);
+          }
+          continue;
+        }
         const int side = a.g.side[l];
         {
           const int R = halo_half_width(a.halo, l, side);
@@ -134,22 +199,7 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
               phi = phi_eval<BASIS>(x, y, a.g.centers[2 * k], a.g.centers[2 * k + 1],
                                     knot_scale(a.g.bw[k], a.g.cal));
             }
-            const uint64_t mask = __ballot(phi != 0.f);
-            const int m = __popcll(mask);
-            if (n + m > LIST - 8) {        // list full: consume it (zero-padded to 8) and start over
-              const int npad = (n + 7) & ~7;
-              if (lane < npad - n) { my_phi[n + lane] = 0.f; my_k[n + lane] = 0; }
-              __builtin_amdgcn_wave_barrier();
-              consume(npad);
-              __builtin_amdgcn_wave_barrier();
-              n = 0;
-            }
-            if (phi != 0.f) {
-              const int pos = n + __popcll(mask & below);
-              my_phi[pos] = phi;
-              my_k[pos] = a.g.p + k;
-            }
-            n += m;
+            push(phi, k);
           }
         }
       }

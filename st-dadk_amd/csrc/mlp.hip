@@ -45,6 +45,7 @@ struct Plan {
   size_t feats; int64_t ldf;           // dense: materialised features
   size_t bw_exp, kpart; int kslabs;    // learnable knots: exp(log_bw) [Ks], per-slab knot partials
   size_t halo;                         // learnable knots, window path: per-level partial maxima of the candidate reach
+  size_t kcs, kperm, kperm_tmp, reach; // scattered knots, window path: per-level cell lists of the knots (knot_bins)
   size_t psi; int ld_psi;              // window: temporal basis [B][ld_psi]
   size_t ypred, dY;                    // [B*Q]
   size_t keys, hist, cursor, cell_start, perm_tmp, perm, xs, ys, ts, y_s, X_s;
@@ -53,7 +54,7 @@ struct Plan {
 };
 
 static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = PLAN_MLP, int p_cov = 0,
-                      int Kt = 0, int64_t Ks_learn = 0) {
+                      int Kt = 0, int64_t Ks_learn = 0, int64_t Ks_scattered = 0, int n_levels = 0) {
   p->L = d->n_hidden;
   p->B = B;
   size_t off = 0;
@@ -143,6 +144,14 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
     p->bw_exp = take((size_t)Ks_learn);
     p->kpart = take((size_t)p->kslabs * 3 * (size_t)Ks_learn);
     p->halo = take((size_t)STDADK_MAX_LEVELS * HALO_SPLIT);
+  }
+  p->kcs = p->kperm = p->kperm_tmp = p->reach = 0;
+  if (mode == PLAN_STEP_WINDOW && Ks_scattered > 0) {
+    p->kcs = take((size_t)n_levels * (KNOT_CELLS * KNOT_CELLS + 1));
+    p->kperm = take((size_t)Ks_scattered);
+    p->kperm_tmp = take((size_t)Ks_scattered);
+    p->reach = take(STDADK_MAX_LEVELS);
+    if (Ks_learn == 0) p->bw_exp = take(1);      // (fixed scattered knots: no exp table)
   }
   if (mode == PLAN_STEP_WINDOW) {
     p->G = pick_cell_grid(B);
@@ -502,6 +511,7 @@ struct Ctx {
   // materialising path, small D: layer 0 starts inside the tail launch from the raw observations (TailDense0)
   bool d0 = false;
   const float *d0_coords = nullptr, *d0_t = nullptr, *d0_X = nullptr, *d0_bw = nullptr;
+  bool scattered = false;       // STDADK_FLAG_SCATTERED: the knots of a level sit anywhere (window path through knot cell lists)
   bool bf16 = false;            // STDADK_FLAG_BF16: bf16 operands in the fused tail kernels (P->W_bf16 / WT_bf16)
   bool cap32 = false;           // this batch's tail launches use <= 32-row tiles (bf16 + dense layer 0 in the launch)
   bool save = true;             // false in eval mode: the forward keeps nothing for a backward (xhat, rstd, act, psi)
@@ -515,6 +525,7 @@ struct Ctx {
   hipStream_t aux = nullptr;
   int (*fork_after_dz)(Ctx &) = nullptr;   // called by run_backward (fused tail) right after the dZ kernel
   const stdadk_basis_desc *basis = nullptr;
+  const stdadk_basis_desc *basis_in = nullptr;   // set by step_common (scattered_bins reads the log-bandwidths)
   bool dw0_forked = false;        // the per-knot gather of dW0^T was forked onto the auxiliary stream
   // extra products C[M][H0] = A^T dZ_0 (reduction over the batch) to run with the dW GEMMs of the
   // fused-tail backward: the temporal / covariate rows of dW0^T on the window path
@@ -909,13 +920,29 @@ static int check_basis(const stdadk_basis_desc *b, const stdadk_mlp_desc *d) {
   STDADK_REQUIRE(b->Kt == 0 || (b->t_centers && b->t_bw), STDADK_E_ARG, "basis desc: temporal knots NULL");
   if (b->n_levels > 0) {
     STDADK_REQUIRE(b->n_levels <= STDADK_MAX_LEVELS, STDADK_E_ARG, "basis desc: too many levels");
-    int64_t k = 0;
+    int64_t k = 0, kc = 0;
     for (int l = 0; l < b->n_levels; ++l) {
       STDADK_REQUIRE(b->side[l] >= 1, STDADK_E_ARG, "basis desc: side[%d] < 1", l);
       k += (int64_t)b->side[l] * b->side[l];
+      kc += b->side[l];
     }
-    STDADK_REQUIRE(k == b->Ks, STDADK_E_SHAPE, "basis desc: sum(side^2)=%lld != Ks=%lld", (long long)k, (long long)b->Ks);
+    // uniform grid: side lengths; STDADK_FLAG_SCATTERED: level sizes (the flag is checked by the callers)
+    STDADK_REQUIRE(k == b->Ks || kc == b->Ks, STDADK_E_SHAPE,
+                   "basis desc: neither sum(side^2)=%lld nor sum(side)=%lld equals Ks=%lld", (long long)k, (long long)kc,
+                   (long long)b->Ks);
   }
+  return 0;
+}
+
+static inline bool is_scattered(const stdadk_basis_desc *b, int flags) {
+  return (flags & STDADK_FLAG_SCATTERED) != 0 && b->n_levels > 0;
+}
+static int check_levels(const stdadk_basis_desc *b, int flags) {
+  if (b->n_levels <= 0) return 0;
+  int64_t k = 0;
+  for (int l = 0; l < b->n_levels; ++l) k += is_scattered(b, flags) ? (int64_t)b->side[l] : (int64_t)b->side[l] * b->side[l];
+  STDADK_REQUIRE(k == b->Ks, STDADK_E_SHAPE, "basis desc: the level sizes add up to %lld, Ks = %lld%s", (long long)k,
+                 (long long)b->Ks, is_scattered(b, flags) ? " (STDADK_FLAG_SCATTERED: side[] holds knot counts)" : "");
   return 0;
 }
 
@@ -930,18 +957,22 @@ static bool want_window(const stdadk_basis_desc *b, const stdadk_mlp_desc *d, in
   // small tables: materialising is cheap (D small) and the window path's per-knot gather is serial over
   // the many rows each coarse knot sees (MI355X, B = 4096, 227 knots: 0.34 ms window vs 0.15 ms dense)
   if (!(flags & STDADK_FLAG_WINDOW) && b->Ks < 1024) return false;
+  if (is_scattered(b, flags) && b->n_levels > STDADK_MAX_LEVELS) return false;
   return l1_window_supported(b->n_levels, b->basis, d->hidden[0], b->p, (int)b->Kt);
 }
 
-static GridView make_grid(const stdadk_basis_desc *b) {
+static GridView make_grid(const stdadk_basis_desc *b, bool scattered = false) {
   static const float cals[3] = {1.000000f, 0.223477f, 0.654714f};   // st_interp.py:56-60
   GridView g;
   g.n_levels = b->n_levels;
+  g.scattered = scattered ? 1 : 0;
   int off = 0;
   for (int l = 0; l < STDADK_MAX_LEVELS; ++l) {
-    g.side[l] = l < b->n_levels ? b->side[l] : 0;
+    const int v = l < b->n_levels ? b->side[l] : 0;
+    g.side[l] = scattered ? 0 : v;
+    g.cnt[l] = scattered ? v : v * v;
     g.off[l] = off;
-    off += g.side[l] * g.side[l];
+    off += g.cnt[l];
   }
   g.p = b->p; g.Ks = (int)b->Ks; g.Kt = (int)b->Kt;
   g.cal = cals[b->basis];
@@ -958,6 +989,24 @@ static BinBuffers plan_bins(float *ws, const Plan &pl) {
   return bb;
 }
 
+// scattered knots: bin the knots of every level into cells (knot_bins) and point the forward at the lists
+static int scattered_bins(Ctx &c, L1FwdArgs &a) {
+  const Plan &pl = c.pl;
+  const stdadk_basis_desc *b = c.basis_in;
+  int *kcs = (int *)(c.ws + pl.kcs), *kperm = (int *)(c.ws + pl.kperm), *ktmp = (int *)(c.ws + pl.kperm_tmp);
+  float *reach = c.ws + pl.reach;
+  int rc;
+  if (c.log_bw) {
+    a.g.bw = c.ws + pl.bw_exp;
+    rc = knot_bins(a.g, kcs, kperm, ktmp, reach, c.st, b->s_bw, c.ws + pl.bw_exp);
+  } else {
+    rc = knot_bins(a.g, kcs, kperm, ktmp, reach, c.st);
+  }
+  if (rc) return rc;
+  a.kcs = kcs; a.kperm = kperm; a.reach = reach; a.Gk = KNOT_CELLS;
+  return 0;
+}
+
 // feature build + layer 0 for the window path (sorted order); returns with act[0] ready
 static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float *coords, const float *t,
                                  const float *X, const float *y) {
@@ -971,9 +1020,13 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
     if (rc) return rc;
   }
   L1FwdArgs a;
-  a.g = make_grid(b);
+  a.g = make_grid(b, c.scattered);
   a.halo = nullptr;
-  if (c.log_bw) {
+  if (c.scattered) {
+    // knots anywhere: this step's cell lists of the knots (and exp(log_bw) for learnable ones)
+    rc = scattered_bins(c, a);
+    if (rc) return rc;
+  } else if (c.log_bw) {
     // learnable knots: bandwidth = exp(log_bandwidth) (st_interp.py:146-148), and the candidate
     // windows follow wherever the knots are now
     a.g.bw = c.ws + pl.bw_exp;
@@ -1076,7 +1129,7 @@ extern "C" size_t stdadk_step_workspace_bytes(const stdadk_basis_desc *b, const 
   if (check_desc(d) != 0 || check_basis(b, d) != 0 || B < 0) return 0;
   Plan p;
   make_plan(d, B > 0 ? B : 1, &p, want_window(b, d, flags) ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt,
-            learn_ks(b, flags));
+            learn_ks(b, flags), is_scattered(b, flags) ? b->Ks : 0, b->n_levels);
   return p.total_floats * sizeof(float);
 }
 
@@ -1089,7 +1142,11 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
   STDADK_REQUIRE(B > 0 && B < (1ll << 31), STDADK_E_ARG, "step: bad B");
   STDADK_REQUIRE(workspace && aligned16(workspace), STDADK_E_ALIGN, "step: workspace NULL or not 16-byte aligned");
   *window = want_window(b, d, flags);
-  make_plan(d, B, &c.pl, *window ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt, learn_ks(b, flags));
+  rc = check_levels(b, flags);
+  if (rc) return rc;
+  c.scattered = *window && is_scattered(b, flags);
+  make_plan(d, B, &c.pl, *window ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt, learn_ks(b, flags),
+            c.scattered ? b->Ks : 0, b->n_levels);
   c.log_bw = (flags & STDADK_FLAG_LOG_BW) != 0;
   c.bf16 = (flags & STDADK_FLAG_BF16) != 0;
   STDADK_REQUIRE(!c.bf16 || (tail_enabled() && d->n_hidden >= 1 && tail_supported(d, 1)), STDADK_E_ARG,
@@ -1098,6 +1155,7 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
   STDADK_REQUIRE(workspace_bytes >= c.pl.total_floats * sizeof(float), STDADK_E_WORKSPACE,
                  "step: workspace %zu < %zu bytes", workspace_bytes, c.pl.total_floats * sizeof(float));
   c.d = d; c.ws = (float *)workspace; c.B = B;
+  c.basis_in = b;
   c.w0t = (flags & STDADK_FLAG_W0_T) != 0;
   c.masks = nullptr;
   c.prebinned = *window && (flags & STDADK_FLAG_PREBINNED) != 0;
@@ -1111,7 +1169,7 @@ static int window_dw0(Ctx &c, hipStream_t st, GemmGroup *with_products = nullptr
   const stdadk_basis_desc *b = c.basis;
   float *ws = c.ws;
   L1BwdArgs a;
-  a.g = make_grid(b);
+  a.g = make_grid(b, c.scattered);
   a.xs = ws + c.pl.xs; a.ys = ws + c.pl.ys;
   a.cell_start = (const int *)(ws + c.pl.cell_start);
   a.G = c.pl.G; a.B = (int)c.B; a.H = c.d->hidden[0];
@@ -1287,8 +1345,12 @@ extern "C" int stdadk_spatial_partial_f32(const stdadk_basis_desc *b, const stda
   rc = bin_obs(coords, coords, nullptr, 0, nullptr, 0, (int)S, pl.G, bb, c.st);
   if (rc) return rc;
   L1FwdArgs a;
-  a.g = make_grid(b);
+  a.g = make_grid(b, c.scattered);
   a.halo = nullptr;
+  if (c.scattered) {
+    rc = scattered_bins(c, a);
+    if (rc) return rc;
+  }
   a.xs = bb.xs; a.ys = bb.ys; a.ts = bb.ts; a.Xs = nullptr;
   a.B = (int)S; a.H = d->hidden[0];
   a.W0T = P->W[0]; a.b0 = P->b[0]; a.gamma = a.beta = nullptr; a.eps = d->ln_eps;

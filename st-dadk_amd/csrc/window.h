@@ -14,6 +14,8 @@ struct GridView {
   int n_levels;
   int side[STDADK_MAX_LEVELS];
   int off[STDADK_MAX_LEVELS];
+  int scattered;         // STDADK_FLAG_SCATTERED: the knots of a level sit anywhere (gmm / random_site initialisers,
+  int cnt[STDADK_MAX_LEVELS];   // st_interp.py:187-343); level l = knots [off[l], off[l] + cnt[l]), side[] unused
   int p;                 // feature column of spatial knot 0
   int Ks, Kt;
   float cal;             // calibration factor of the basis
@@ -60,6 +62,14 @@ struct L1FwdArgs {
   // grid cell, from the device floats [level][HALO_SPLIT] written by knot_halo() every step (see
   // halo_half_width); NULL = fixed grid knots (R = 3)
   const float *halo;
+  // scattered knots (g.scattered): per level the knots binned into a Gk x Gk cell grid by knot_bins() --
+  // kcs[l][Gk*Gk + 1] first position of every cell in kperm (positions are global: level l's run starts at
+  // g.off[l]), kperm[Ks] the knot ids cell by cell (ascending inside a cell), reach[l] = max support radius of
+  // the level.  An observation's candidates are the knots of the cells within ceil(reach Gk) + 1 of its own.
+  const int *kcs = nullptr;
+  const int *kperm = nullptr;
+  const float *reach = nullptr;
+  int Gk = 0;
   // raw != 0: only the spatial part of the pre-activation, sum_k phi_k(s) W0^T[p+k,:] (no bias, no temporal
   // rows, no LayerNorm/ReLU/Dropout), written to act -- the per-site half of a site x time prediction grid
   int raw = 0;
@@ -87,6 +97,14 @@ struct L1BwdArgs {
   const float *W0T;
   float *kpart;
 };
+
+// Scattered knots: counting sort of every level's knots into a Gk x Gk cell grid (one workgroup per level;
+// in-cell order by knot id, so the lists -- and with them every sum the forward takes in list order -- do not
+// depend on the arrival order of the atomics), plus the level's largest support radius.  Runs every step: learnable
+// knots move.  log_bw (optional): the bandwidths are given as logs; exp() of them is also written to bw_out.
+constexpr int KNOT_CELLS = 32;     // Gk
+int knot_bins(const GridView &g, int *kcs, int *kperm, int *kperm_tmp, float *reach, hipStream_t st,
+              const float *log_bw = nullptr, float *bw_out = nullptr);
 
 // Per level: R = ceil(max_k (s_k + |c_k - grid_k|_inf) * (side-1)), the half-width (in grid cells) of the
 // candidate window that is guaranteed to contain every knot whose support reaches an observation,

@@ -384,6 +384,95 @@ int knot_halo(const GridView &g, float *halo, hipStream_t st, const float *log_b
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// scattered knots: per-level cell lists of the KNOTS (see knot_bins in window.h)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void knot_bin_kernel(GridView g, int *__restrict__ kcs, int *__restrict__ kperm,
+                                                        int *__restrict__ kperm_tmp, float *__restrict__ reach,
+                                                        const float *__restrict__ log_bw, float *__restrict__ bw_out) {
+  constexpr int Gk = KNOT_CELLS, NC = Gk * Gk;
+  static_assert(NC == 1024, "one thread per cell");
+  __shared__ int hist[NC];          // counts, then running cursors
+  __shared__ int start[NC + 1];
+  __shared__ int part[32];
+  __shared__ float fred[16];
+  const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int off = g.off[l], n = g.cnt[l];
+  hist[tid] = 0;
+  __syncthreads();
+  float m = 0.f;
+  for (int j = tid; j < n; j += 1024) {
+    const int k = off + j;
+    float bwk;
+    if (log_bw) { bwk = expf(log_bw[k]); bw_out[k] = bwk; } else { bwk = g.bw[k]; }
+    const float v = bwk * g.cal;
+    m = fmaxf(m, (v == v) ? v : 3.0e38f);                  // a NaN bandwidth reaches everywhere
+    atomicAdd(&hist[cell_of(g.centers[2 * k], g.centers[2 * k + 1], Gk)], 1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) fred[wv] = m;
+  __syncthreads();
+  if (tid == 0) {
+    float r = 0.f;
+    for (int w = 0; w < 16; ++w) r = fmaxf(r, fred[w]);
+    reach[l] = r;
+  }
+  // exclusive scan of the 1024 cell counts: one per thread
+  const int cnt = hist[tid];
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) part[wv] = incl;
+  __syncthreads();
+  if (tid < 16) {
+    int tot = part[tid];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int u = __shfl_up(tot, o, 64);
+      if (tid >= o) tot += u;
+    }
+    part[16 + tid] = tot;
+  }
+  __syncthreads();
+  const int s0 = incl - cnt + (wv > 0 ? part[16 + wv - 1] : 0);
+  start[tid] = s0;
+  if (tid == 1023) start[NC] = s0 + cnt;
+  hist[tid] = s0;                                           // cursor
+  int *cs = kcs + (size_t)l * (NC + 1);
+  cs[tid] = off + s0;
+  if (tid == 1023) cs[NC] = off + s0 + cnt;
+  __syncthreads();
+  for (int j = tid; j < n; j += 1024) {
+    const int k = off + j;
+    const int pos = atomicAdd(&hist[cell_of(g.centers[2 * k], g.centers[2 * k + 1], Gk)], 1);
+    kperm_tmp[off + pos] = k;
+  }
+  __syncthreads();            // vmcnt(0) + barrier: the workgroup's own global stores are visible to it
+  // one thread per cell: rank its knots by id (the scatter's arrival order must not show)
+  {
+    const int a0 = start[tid], a1 = start[tid + 1];
+    for (int i = a0; i < a1; ++i) {
+      const int k = kperm_tmp[off + i];
+      int rank = 0;
+      for (int j = a0; j < a1; ++j) rank += kperm_tmp[off + j] < k;
+      kperm[off + a0 + rank] = k;
+    }
+  }
+}
+
+int knot_bins(const GridView &g, int *kcs, int *kperm, int *kperm_tmp, float *reach, hipStream_t st,
+              const float *log_bw, float *bw_out) {
+  STDADK_REQUIRE(g.scattered && g.n_levels > 0 && kcs && kperm && kperm_tmp && reach, STDADK_E_ARG, "knot_bins: bad arguments");
+  STDADK_REQUIRE(!log_bw || bw_out, STDADK_E_ARG, "knot_bins: log_bw needs bw_out");
+  STDADK_LAUNCH(knot_bin_kernel, dim3((unsigned)g.n_levels), dim3(1024), 0, st, g, kcs, kperm, kperm_tmp, reach, log_bw, bw_out);
+  STDADK_CHECK_LAUNCH("knot_bins");
+  return 0;
+}
+
 bool l1_window_supported(int n_levels, int basis, int H, int p, int Kt) {
   if (n_levels <= 0 || n_levels > STDADK_MAX_LEVELS) return false;
   if (basis != STDADK_BASIS_WENDLAND && basis != STDADK_BASIS_TRIANGULAR) return false;  // compact support
@@ -428,7 +517,7 @@ static int l1_group(const L1FwdArgs &a) {
 
 template <int CPL, bool LN, int BASIS>
 static int launch_fwd(const L1FwdArgs &a, hipStream_t st) {
-  if (a.halo) return launch_fwd_t<CPL, LN, BASIS, true, 1>(a, st);
+  if (a.halo || a.kperm) return launch_fwd_t<CPL, LN, BASIS, true, 1>(a, st);
   return l1_group(a) == 2 ? launch_fwd_t<CPL, LN, BASIS, false, 2>(a, st)
                           : launch_fwd_t<CPL, LN, BASIS, false, 1>(a, st);
 }
@@ -487,7 +576,7 @@ int knot_group_count(const GridView &g, int nk) {
 // side is a multiple of 8); environment STDADK_KNOT_XCD=0 switches the striping off (diagnostic)
 int knot_xcd_slots(const GridView &g, int nk) {
   const char *e = getenv("STDADK_KNOT_XCD");
-  if ((e && e[0] == '0') || (nk != 1 && nk != 2)) return 0;
+  if ((e && e[0] == '0') || (nk != 1 && nk != 2) || g.scattered) return 0;
   int most = 0;
   for (int x = 0; x < 8; ++x) {
     int n = 0;
@@ -505,7 +594,7 @@ int knot_xcd_slots(const GridView &g, int nk) {
 // -2.5 us on the merged weight-gradient launch at B = 4096 and -14 % on it at B = 65 536; blocks of 2 x 2
 // (the body supports NK = 4) are slower than pairs up to B = 16 384 and no faster at 65 536.
 int knots_per_wave(const L1BwdArgs &a) {
-  if (a.kpart) return 1;
+  if (a.kpart || a.g.scattered) return 1;
   int nk = 2;
   if (const char *e = getenv("STDADK_KNOTS_PER_WAVE")) {
     const int v = atoi(e);

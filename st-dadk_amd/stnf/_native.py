@@ -96,6 +96,8 @@ FLAG_LOG_BW = 4
 FLAG_WINDOW = 8
 FLAG_PREBINNED = 16
 FLAG_BF16 = 32
+FLAG_SCATTERED = 64
+KNOT_CELLS = 32          # cells per axis of the knot cell lists (csrc/window.h)
 
 _lib = None
 
@@ -378,7 +380,8 @@ def gemm(A, a_km, Bm, b_km, M, N, K, bias=None, out=None, workspace=None):
 
 
 def make_basis(p, basis, sides, s_centers, s_bw, t_centers, t_bw):
-    """ABI descriptor of the knot tables; `sides` = level side lengths of a uniform grid or None."""
+    """ABI descriptor of the knot tables; `sides` = level side lengths of a uniform grid, or (with FLAG_SCATTERED)
+    the knot COUNT of every level of a scattered table, or None."""
     b = BasisDesc()
     b.p, b.basis = int(p), BASIS_KIND[basis]
     b.n_levels = len(sides) if sides else 0

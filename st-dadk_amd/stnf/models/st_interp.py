@@ -484,15 +484,43 @@ class STInterpMLP(nn.Module):
     def _native_tensors(self):
         return self._pack([p.data for p in self._body_params()] + (list(self._delta_head()) if self._has_delta else []))
 
+    def _scattered_levels(self):
+        """Level sizes for the window path over SCATTERED knots (gmm / random_site tables), or None when that path
+        does not apply or would not pay: compact-support basis, at least 1024 knots, at most 8 levels, and the
+        expected number of candidates per observation -- per level the knots of the cells within the largest support
+        radius, (2 (ceil(reach Gk) + 1) + 1)^2 of Gk^2 cells -- at most 35 % of the table (beyond that the
+        materialising kernels' dense sweep is the better program).  Taken from the bandwidths as they are now."""
+        sb = self.spatial_basis
+        if sb.init_method == 'uniform' or self.spatial_basis_function not in ('wendland', 'triangular'):
+            return None
+        if len(sb.n_centers) > 8 or self.force_dense_path:
+            return None
+        if self.force_window_path:                 # diagnostics / tests: the window kernels regardless of the estimate
+            return list(sb.n_centers)
+        if sb.k < 1024:
+            return None
+        cal = sb.CALIBRATION_FACTORS[self.spatial_basis_function]
+        with torch.no_grad():
+            bw = sb.bandwidths.detach().float().cpu()
+        Gk, cand, o = N.KNOT_CELLS, 0.0, 0
+        for n in sb.n_centers:
+            reach = float(bw[o:o + n].max()) * cal
+            o += n
+            if not math.isfinite(reach):
+                return None
+            span = min(2 * (math.ceil(reach * Gk) + 1) + 1, Gk)
+            cand += n * (span / Gk) ** 2
+        return list(sb.n_centers) if cand <= 0.35 * sb.k else None
+
     def _basis_desc(self):
         sb, tb = self.spatial_basis, self.temporal_basis
+        sides = sb.level_sides if sb.init_method == 'uniform' else self._scattered_levels()
         if sb.learnable:
             # the bandwidth slot carries log-bandwidths (FLAG_LOG_BW); knots that started as the uniform
-            # grid keep their grid indexing, which lets the window path follow them as they move
-            sides = sb.level_sides if sb.init_method == 'uniform' else None
+            # grid keep their grid indexing, which lets the window path follow them as they move; scattered
+            # tables are re-binned into cell lists every step
             return N.make_basis(self.p, self.spatial_basis_function, sides, sb.centers.data,
                                 sb.log_bandwidths.data, tb.centers, tb.bandwidths)
-        sides = sb.level_sides if sb.init_method == 'uniform' else None
         return N.make_basis(self.p, self.spatial_basis_function, sides, sb.centers, sb._bandwidths,
                             tb.centers, tb.bandwidths)
 
@@ -514,6 +542,8 @@ class STInterpMLP(nn.Module):
         flags = N.FLAG_DENSE if force_dense else (N.FLAG_WINDOW if self.force_window_path else 0)
         if self.spatial_basis.learnable:
             flags |= N.FLAG_LOG_BW
+        if self.spatial_basis.init_method != 'uniform' and st.basis.n_levels > 0:
+            flags |= N.FLAG_SCATTERED         # the descriptor's level entries are knot counts
         if not w0.is_contiguous() and w0.t().is_contiguous():
             tensors[0] = w0.t()                                  # engine-owned (in,out) storage
             flags |= N.FLAG_W0_T

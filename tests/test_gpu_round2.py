@@ -520,3 +520,127 @@ def test_two_rank_run_epoch_equals_single_process_union(sizes, B, learn):
     assert abs(losses[-1] - ref_losses[-1]) <= 0.05 * abs(ref_losses[-1])
     # (Adam's m/sqrt(v) turns rounding-level differences of near-zero gradient entries into lr-sized updates)
     assert T.rel_l2(flat, eng.flat.cpu().numpy()) <= 1e-4
+
+
+# ------------------------------------------------------------------ scattered (non-grid) knots on the window path
+def _scattered_model(sizes, basis, learnable, seed, hidden=(256, 128)):
+    """Knots drawn from scattered sites (random_site initialiser, st_interp.py:266-343) plus a few pushed outside
+    the unit square and a few with doubled bandwidths; golden-style deterministic weights."""
+    from stnf.models import STInterpMLP
+    rs = np.random.RandomState(seed)
+    pts = np.concatenate([rs.uniform(0, 1, (12000, 2)), 0.3 + 0.05 * rs.standard_normal((6000, 2))]).astype(np.float32)
+    np.random.seed(seed)
+    cfg = dict(p=0, k_spatial_centers=list(sizes), k_temporal_centers=[10, 15], hidden_dims=list(hidden),
+               layernorm=True, basis=basis, output_dim=1, B=0, seed=seed)
+    m = STInterpMLP(p=0, k_spatial_centers=cfg["k_spatial_centers"], k_temporal_centers=cfg["k_temporal_centers"],
+                    hidden_dims=cfg["hidden_dims"], dropout=0.0, layernorm=True, spatial_learnable=learnable,
+                    spatial_init_method="random_site", spatial_basis_function=basis, train_coords=pts)
+    st = cases.make_state(cfg)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k in st:
+                p.copy_(torch.from_numpy(st[k].copy()))
+        sb = m.spatial_basis
+        c = sb.centers
+        c[3] = torch.tensor([-0.04, 0.5]); c[7] = torch.tensor([1.03, -0.02]); c[11] = torch.tensor([0.5, 1.06])
+        if learnable:
+            sb.log_bandwidths[5] += math.log(2.0); sb.log_bandwidths[100] += math.log(1.7)
+        else:
+            sb._bandwidths[5] *= 2.0; sb._bandwidths[100] *= 1.7
+    return m.to(dev()), cfg, st
+
+
+import math  # noqa: E402
+
+
+@pytest.mark.parametrize("basis,learnable,B", [("wendland", True, 300), ("wendland", True, 4096), ("wendland", True, 9000),
+                                               ("wendland", False, 300), ("wendland", False, 4096), ("wendland", False, 9000),
+                                               ("triangular", False, 4096), ("triangular", True, 300)])
+def test_scattered_knots_window_path_matches_materialised_and_oracle(basis, learnable, B):
+    """5 120 non-grid knots in two levels (1024 + 4096): the window kernels over per-level knot cell lists
+    (STDADK_FLAG_SCATTERED) against the materialising kernels and the float64 oracle -- y, loss, every gradient
+    (knot gradients included when learnable).  Knots outside the unit square and knots with inflated bandwidths
+    are in the table; the three batch sizes take the one-launch step kernel, the separate kernels and the
+    64-row-tile kernels.  (Learnable TRIANGULAR knots only at 300 rows: phi' jumps from -1 to 0 at r = 1, so among
+    the ~half a million supported pairs of a 9 000-row batch the one pair that fp32 and float64 put on different
+    sides of r = 1 moves the whole centre gradient by 7e-4 -- a property of that basis, not of a kernel.)"""
+    d = dev()
+    res = {}
+    for path in ("window", "dense"):
+        m, cfg, st = _scattered_model([1024, 4096], basis, learnable, 77)
+        cfg["B"] = B
+        X, coords, t, y = cases.make_inputs(cfg)
+        m.force_dense_path = path == "dense"
+        desc = m._basis_desc()
+        assert (desc.n_levels == 2 and desc.side[0] == 1024 and desc.side[1] == 4096) if path == "window" else desc.n_levels == 0
+        st_ = m._step_state(d, force_dense=m.force_dense_path)
+        from stnf import _native as N
+        assert N.step_uses_window(st_.basis, st_.desc, st_.flags) == (path == "window")
+        m.train()
+        yp = m(None, torch.from_numpy(coords).to(d), torch.from_numpy(t).to(d))
+        loss = torch.nn.functional.mse_loss(yp, torch.from_numpy(y).to(d))
+        loss.backward()
+        res[path] = (yp.detach().cpu().numpy(), loss.item(), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}, m)
+    yw, lw, gw, m = res["window"]
+    yd, ld, gd, _ = res["dense"]
+    assert np.abs(yw - yd).max() <= 2e-6 * max(1.0, np.abs(yd).max()) and abs(lw - ld) <= 2e-6 * ld
+    for k in gd:
+        # (knot gradients: sum_b q_b (dZ_b . w_k) taken as (sum_b q_b dZ_b) . w_k on the window path, per row on the
+        #  materialising path -- fp32 cancellation differs; the triangular q does not taper towards the support's edge)
+        assert T.rel_l2(gw[k], gd[k]) <= (5e-5 if k.startswith("spatial_basis.") else 5e-6), k
+    sb = m.spatial_basis
+    cen = sb.centers.detach().cpu().numpy().astype(np.float64)
+    if learnable:
+        params = dict(st)
+        params["spatial_basis.centers"] = sb.centers.detach().cpu().numpy()
+        params["spatial_basis.log_bandwidths"] = sb.log_bandwidths.detach().cpu().numpy()
+        yo, lo, go = orc.learnable_step_grads(X, coords, t, y, params, cfg, {}, params["spatial_basis.centers"])
+    else:
+        tc = m.temporal_basis.centers.cpu().numpy(); tb = m.temporal_basis.bandwidths.cpu().numpy()
+        feat = orc.features(X, orc.spatial_basis(coords, cen, sb.bandwidths.cpu().numpy(), basis),
+                            orc.temporal_basis(t, tc, tb), 0)
+        yo, cache = orc.mlp_forward(feat, st, len(cfg["hidden_dims"]), True)
+        go = orc.mlp_mse_backward(yo, y, cache, st, len(cfg["hidden_dims"]), True)
+        lo = orc.mse(yo, y)
+    assert np.abs(yw - yo).max() <= TOL * max(1.0, np.abs(yo).max()) and abs(lw - lo) <= TOL * lo
+    for k in gw:
+        assert T.rel_l2(gw[k], go[k]) <= 2e-5, (k, T.rel_l2(gw[k], go[k]))
+
+
+def test_scattered_knots_engine_and_grid_inference():
+    """The fused engine on scattered learnable knots (knot cell lists rebuilt every step as the knots move): three
+    steps on the window path == the materialising path; the default path choice takes the window kernels for this
+    table (small supports) and the materialising ones when the bandwidths are inflated to cover the domain; and
+    fixed scattered knots through Predictor.predict_grid (per-site half of layer 0 on the window path) == row by row."""
+    from stnf.engine import TrainStep, Predictor
+    d = dev()
+    flats = []
+    for dense in (False, True):
+        m, cfg, st = _scattered_model([1024, 4096], "wendland", True, 78)
+        cfg["B"] = 4096
+        X, coords, t, y = (torch.from_numpy(a).to(d) for a in cases.make_inputs(cfg))
+        m.train()
+        eng = TrainStep(m, lr=1e-3, ema_decay=0.99, max_batch=4096, force_dense=dense, domain_penalty_weight=0.01,
+                        movement_penalty_weight=0.02)
+        assert eng.uses_window == (not dense)
+        for _ in range(3):
+            eng.step(None, coords, t, y)
+        flats.append((eng.mean_loss(), eng.flat.clone()))
+    assert abs(flats[0][0] - flats[1][0]) <= 1e-5 * abs(flats[1][0])
+    assert T.rel_l2(flats[0][1].cpu().numpy(), flats[1][1].cpu().numpy()) <= 5e-5
+    # supports as wide as the domain: the estimate sends the table to the materialising kernels
+    m2, _, _ = _scattered_model([1024, 4096], "wendland", True, 79)
+    with torch.no_grad():
+        m2.spatial_basis.log_bandwidths.fill_(0.0)
+    assert m2._basis_desc().n_levels == 0 and not TrainStep(m2, max_batch=256).uses_window
+    # fixed scattered knots: site x time grid
+    m3, cfg3, _ = _scattered_model([1024, 4096], "triangular", False, 80)
+    m3.eval()
+    g = torch.Generator().manual_seed(4)
+    S, Tn = 5001, 3
+    sites = torch.rand(S, 2, generator=g).to(d)
+    tv = torch.linspace(0, 1, Tn).to(d)
+    pr = Predictor(m3, chunk=2048)
+    yg = pr.predict_grid(sites, tv)
+    yr = pr.predict(sites.repeat(Tn, 1), tv.repeat_interleave(S)).view(Tn, S, 1)
+    assert (yg - yr).abs().max().item() <= 2e-6 * max(1.0, yr.abs().max().item())

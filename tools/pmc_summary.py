@@ -24,9 +24,19 @@ def per_kernel(d, counter):
         if "stdadk::" not in name:
             continue
         short = re.sub(r"^void ", "", name).split("(")[0].replace("stdadk::", "")
-        a = acc.setdefault(short, [0, 0.0])
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
+        # a kernel launched at several grid sizes in one run (rbf_build: the bench batch and the past-L3 footprint)
+        # is also kept per grid size, "<kernel>@<threads in the grid>"
+        for key in (short, f"{short}@{r.get('Grid_Size', '?')}"):
+            a = acc.setdefault(key, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    grids = {}
+    for k in acc:
+        if "@" in k:
+            grids.setdefault(k.split("@")[0], []).append(k)
+    for base, ks in grids.items():          # one grid size only: the per-grid entry says nothing new
+        if len(ks) == 1:
+            del acc[ks[0]]
     return {k: (n, tot / n) for k, (n, tot) in acc.items()}
 
 
@@ -41,8 +51,9 @@ for k in sorted(set(F) | set(W)):
     n, f = F.get(k, (0, 0.0))
     _, w = W.get(k, (0, 0.0))
     traffic = (2 * f + w) * 1024
-    kern[re.sub(r"<.*", "", k)] = traffic
-    full[re.sub(r"<.*", "", k)] = k
+    short = re.sub(r"<[^@]*", "", k)
+    kern[short] = traffic
+    full[short] = k
     lines.append(f"| `{k}` | {n} | {f:.1f} | {w:.1f} | {traffic / 1e6:.1f} |")
 open(out_md, "w").write("\n".join(lines) + "\n")
 json.dump({"note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, C2 B=4096). "
