@@ -558,6 +558,14 @@ def main():
                             output_dim=5),
                 dict(loss="pinball", quantile_levels=taus, non_crossing_weight=0.5, domain_penalty_weight=0.01))
             out["variants"]["ref_default_227_uniform_mse"] = timed(B, 60, dict(k_spatial_centers=[25, 81, 121]))
+            # DA-STDK with NON-GRID knots at the C2 table size (random_site initialiser: knots drawn from the sites,
+            # learnable): the window kernels over per-level knot cell lists against the materialising kernels
+            np.random.seed(1)
+            sc_kw = dict(spatial_learnable=True, spatial_init_method="random_site", train_coords=site,
+                         gradient_damping=True, damping_threshold=0.0, damping_strength=5.0)
+            out["variants"]["scattered_knots_learnable"] = {
+                "window_cell_lists": timed(B, 30, sc_kw, dict(domain_penalty_weight=0.01)),
+                "materialised": timed(B, 15, sc_kw, dict(domain_penalty_weight=0.01, force_dense=True))}
             # A10: dense-grid inference (forward only, eval mode) on the
             # resident observations, as the dense-grid prediction callers run it
             from stnf.engine import Predictor
