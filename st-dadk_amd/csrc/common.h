@@ -69,10 +69,21 @@ __device__ __forceinline__ uint32_t mix32(uint64_t x) {
   x ^= x >> 33;
   return (uint32_t)x;
 }
-__device__ __forceinline__ bool drop_keep(uint64_t seed, int layer, int64_t elem, float p) {
-  uint32_t h = mix32(seed ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(layer + 1)) ^ ((uint64_t)elem * 0xD1B54A32D192ED03ULL));
-  // uniform in [0,1): keep when u >= p  (P(keep) = 1-p)
-  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+// Two stages: a 64-bit mix per (seed, layer, ROW) -- once per row, wave-uniform wherever a wave owns a row, so it
+// runs on the scalar unit -- and a 32-bit finisher per column (two multiplies, three xor-shifts).  The 64-bit mix
+// per ELEMENT that this replaced was ~40 vector instructions of the ~60 a LayerNorm-phase element costs: with four
+// rows per wave (64-row tiles) those phases were bound by vector issue, not by memory (round-2 stamps).
+__device__ __forceinline__ uint32_t drop_rowkey(uint64_t seed, int layer, int64_t row) {
+  return mix32(seed ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(layer + 1)) ^ ((uint64_t)row * 0xD1B54A32D192ED03ULL));
+}
+// keep when u >= p for u = (h >> 8) / 2^24 uniform in [0,1), i.e. (h >> 8) >= ceil(p 2^24)   (P(keep) = 1-p)
+__device__ __forceinline__ uint32_t drop_threshold(float p) { return (uint32_t)ceilf(p * 16777216.0f); }
+__device__ __forceinline__ bool drop_keep(uint32_t rowkey, int col, uint32_t thr) {
+  uint32_t h = rowkey ^ ((uint32_t)col * 0x9E3779B1u);
+  h ^= h >> 16; h *= 0x21f0aaadu;
+  h ^= h >> 15; h *= 0x735a2d97u;
+  h ^= h >> 15;
+  return (h >> 8) >= thr;
 }
 
 }  // namespace stdadk

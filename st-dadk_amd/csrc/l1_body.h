@@ -78,6 +78,7 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
   float *my_psi = lpsi + wave * Kt_pad;
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint32_t drop_thr = drop_threshold(a.drop_p);
   const uint64_t below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
 
   for (int row = r0 + wave; row < r1; row += FW_T / 64) {
@@ -287,13 +288,14 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
       if (lane == 0 && a.rstd) a.rstd[row] = rs;
     }
     float xh[CPL], av[CPL];
+    const uint32_t rowkey = drop_rowkey(seed, 0, row);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       xh[c] = LN ? (acc[c] - mean) * rs : acc[c];
       float u = LN ? fmaf(xh[c], gam[c], bet[c]) : xh[c];
       float v = fmaxf(u, 0.f);
       if (a.drop_p > 0.f) {
-        bool keep = drop_keep(seed, 0, (int64_t)row * H + CPL * lane + c, a.drop_p);
+        bool keep = drop_keep(rowkey, CPL * lane + c, drop_thr);
         v = keep ? v * keep_scale : 0.f;
       }
       av[c] = v;
@@ -341,6 +343,7 @@ __device__ __forceinline__ void l1_window_fwd_multi_body(const L1FwdArgs &a, flo
   float *my_psi = lpsi + wave * Kt_pad * R;
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint32_t drop_thr = drop_threshold(a.drop_p);
   const uint64_t below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
   const int bdx = lane >> 3, bdy = lane & 7;              // this lane's place in an 8 x 8 candidate box
 
@@ -544,13 +547,14 @@ __device__ __forceinline__ void l1_window_fwd_multi_body(const L1FwdArgs &a, flo
         }
         typename VecT<CPL>::T o1, o2;
         float *f1 = reinterpret_cast<float *>(&o1), *f2 = reinterpret_cast<float *>(&o2);
+        const uint32_t rowkey = drop_rowkey(seed, 0, orow);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           const float xh = LN ? (acc[r][c] - mean) * rs : acc[r][c];
           const float u = LN ? fmaf(xh, gam[c], bet[c]) : xh;
           float v = fmaxf(u, 0.f);
           if (a.drop_p > 0.f) {
-            const bool keep = drop_keep(seed, 0, (int64_t)orow * H + CPL * lane + c, a.drop_p);
+            const bool keep = drop_keep(rowkey, CPL * lane + c, drop_thr);
             v = keep ? v * keep_scale : 0.f;
           }
           f1[c] = xh; f2[c] = v;

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_fwd_kernel(
     if (lane == 0) rstd_out[row] = rs;
   }
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const uint32_t rowkey = drop_rowkey(seed, layer, row), drop_thr = drop_threshold(drop_p);
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     int c = lane + 64 * j;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_fwd_kernel(
       float a = fmaxf(u, 0.f);
       if (drop_p > 0.f) {
         int64_t e = row * h + c;
-        bool keep = mask ? (mask[e] != 0) : drop_keep(seed, layer, e, drop_p);
+        bool keep = mask ? (mask[e] != 0) : drop_keep(rowkey, c, drop_thr);
         a = keep ? a * keep_scale : 0.f;
       }
       xhat[row * h + c] = xh;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_bwd_kernel(
     if (row >= B) break;
     float du[CPL], xh[CPL];
     float s1 = 0.f, s2 = 0.f;
+    const uint32_t rowkey = drop_rowkey(seed, layer, row), drop_thr = drop_threshold(drop_p);
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       int c = lane + 64 * j;
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_bwd_kernel(
         float u = LN ? fmaf(x, gamma[c], beta[c]) : x;
         float d = dA[e];
         if (drop_p > 0.f) {
-          bool keep = mask ? (mask[e] != 0) : drop_keep(seed, layer, e, drop_p);
+          bool keep = mask ? (mask[e] != 0) : drop_keep(rowkey, c, drop_thr);
           d = keep ? d * keep_scale : 0.f;
         }
         d = u > 0.f ? d : 0.f;

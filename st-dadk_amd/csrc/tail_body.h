@@ -329,6 +329,7 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
   lds_barrier();
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint32_t drop_thr = drop_threshold(a.drop_p);
   float *cur = act0, *nxt = act1;
   STAMP(1);
   // output-layer weights of q = 0 (the MSE head has Q = 1): requested now, used at the very end
@@ -422,6 +423,7 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
         rs = 1.0f / sqrtf(wave_sum(sq) / (float)h + a.eps);
         if (lane == 0 && grow < a.B && L.rstd) L.rstd[grow] = rs;
       }
+      const uint32_t rowkey = drop_rowkey(seed, L.layer_id, grow);
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int col = lane + 64 * cc;
@@ -429,7 +431,7 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
         const float u = fmaf(xh, gv[cc], bev[cc]);
         float v = fmaxf(u, 0.f);
         if (a.drop_p > 0.f) {
-          const bool keep = drop_keep(seed, L.layer_id, (int64_t)grow * h + col, a.drop_p);
+          const bool keep = drop_keep(rowkey, col, drop_thr);
           v = keep ? v * keep_scale : 0.f;
         }
         if (col < h) {
@@ -571,26 +573,59 @@ __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem,
   {
     float *ph = a.part_head + (size_t)tile * a.Q * (hl + 1);
     const int nrow = min(R, a.B - row0);
-    for (int col = tid; col < hl; col += TT) {
-      float pw[TAIL_MAXQ];
+    if constexpr (MT == 1) {
+      for (int col = tid; col < hl; col += TT) {
+        float pw[TAIL_MAXQ];
 #pragma unroll
-      for (int qq = 0; qq < TAIL_MAXQ; ++qq) pw[qq] = 0.f;
-      // 16 rows of the last activations in flight at a time (clamped rows: sdy is 0 beyond the batch)
-#pragma unroll
-      for (int rb = 0; rb < R; rb += 16) {
+        for (int qq = 0; qq < TAIL_MAXQ; ++qq) pw[qq] = 0.f;
+        // 16 rows of the last activations in flight at a time (clamped rows: sdy is 0 beyond the batch)
         float av[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          av[r] = a.act_last[(size_t)min(row0 + rb + r, a.B - 1) * hl + col];
+          av[r] = a.act_last[(size_t)min(row0 + r, a.B - 1) * hl + col];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
           for (int qq = 0; qq < TAIL_MAXQ; ++qq)
-            if (qq < a.Q) pw[qq] = fmaf(sdy[(rb + r) * a.Q + qq], av[r], pw[qq]);
-      }
+            if (qq < a.Q) pw[qq] = fmaf(sdy[r * a.Q + qq], av[r], pw[qq]);
 #pragma unroll
-      for (int qq = 0; qq < TAIL_MAXQ; ++qq)
-        if (qq < a.Q) ph[qq * hl + col] = pw[qq];
+        for (int qq = 0; qq < TAIL_MAXQ; ++qq)
+          if (qq < a.Q) ph[qq * hl + col] = pw[qq];
+      }
+    } else {
+      // 32 / 64 rows: the column sums over the tile's rows by ALL waves -- four groups of 256 threads take a
+      // quarter of the rows each (one batch of R/4 loads in flight per thread), their partials meet in LDS (the
+      // second gradient tile, or the column-partial scratch under bf16 operands: both unused until the first
+      // LayerNorm phase).  With the columns alone (128 threads of 1024 walking 64 rows in four dependent
+      // batches) this phase was 14 of the backward's 75 us per 64-row tile (round-2 stamps).
+      constexpr int NG = TT / 256, RG = R / NG;
+      float *scr = BF ? red_own : d1;                    // [NG][Q][256]
+      const int g = tid >> 8, col = tid & 255;
+      if (col < hl) {
+        float pw[TAIL_MAXQ];
+#pragma unroll
+        for (int qq = 0; qq < TAIL_MAXQ; ++qq) pw[qq] = 0.f;
+        float av[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+          av[r] = a.act_last[(size_t)min(row0 + g * RG + r, a.B - 1) * hl + col];
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+          for (int qq = 0; qq < TAIL_MAXQ; ++qq)
+            if (qq < a.Q) pw[qq] = fmaf(sdy[(g * RG + r) * a.Q + qq], av[r], pw[qq]);
+#pragma unroll
+        for (int qq = 0; qq < TAIL_MAXQ; ++qq)
+          if (qq < a.Q) scr[(g * TAIL_MAXQ + qq) * 256 + col] = pw[qq];
+      }
+      lds_barrier();
+      for (int i = tid; i < a.Q * hl; i += TT) {
+        const int qq = i / hl, c2 = i - qq * hl;
+        float t = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < NG; ++gg) t += scr[(gg * TAIL_MAXQ + qq) * 256 + c2];     // fixed order
+        ph[qq * hl + c2] = t;
+      }
     }
     if (tid < a.Q) {
       float sb = 0.f;
@@ -601,6 +636,7 @@ __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem,
   lds_barrier();
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint32_t drop_thr = drop_threshold(a.drop_p);
   float *cur = d0, *nxt = d1;
   STAMP(1);                     // head phase done (dA of the last layer, dWo / dbo partials)
 
@@ -625,6 +661,7 @@ __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem,
       const bool valid = grow < a.B;
       float dxh[4];
       float s1 = 0.f, s2 = 0.f;
+      const uint32_t rowkey = drop_rowkey(seed, L.layer_id, grow);
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int col = lane + 64 * cc;
@@ -633,7 +670,7 @@ __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem,
         const float u = fmaf(x, gv[cc], bev[cc]);
         float d = cur[row * ACT_LD + min(col, TAIL_MAX_W - 1)];
         if (a.drop_p > 0.f) {
-          const bool keep = drop_keep(seed, L.layer_id, (int64_t)grow * h + col, a.drop_p);
+          const bool keep = drop_keep(rowkey, col, drop_thr);
           d = keep ? d * keep_scale : 0.f;
         }
         d = (ok && u > 0.f) ? d : 0.f;

@@ -1685,18 +1685,25 @@ def test_dense_layer0_inside_tail_launch(name, monkeypatch):
             monkeypatch.setenv("STDADK_NO_DENSE0_TAIL", "1")
         m = build_model(cfg, dropout=0.1)
         m.train()
-        eng = TrainStep(m, lr=1e-3, ema_decay=0.99, max_batch=n, force_dense=True, seed=0x5DEECE66D)
+        # lr = 0: the parameters stay put, so every step compares the two routes' GRADIENTS on identical weights
+        # (with a real lr, Adam turns summation-order noise in near-zero gradient entries into lr-sized parameter
+        #  differences that depend on the mask draw: 2e-6 .. 8e-5 after three steps)
+        eng = TrainStep(m, lr=0.0, weight_decay=0.0, ema_decay=0.99, max_batch=n, force_dense=True, seed=0x5DEECE66D)
         assert not eng.uses_window
+        grads = []
         for _ in range(3):
             eng.step(X2, c2, t2, y2)
+            grads.append(eng.grad.clone())
         loss = eng.mean_loss()
         m.eval()
         with torch.no_grad():
             ye = m(X2, c2, t2).clone()        # engine-owned (in,out) storage: the eval forward takes the same path
-        res.append((loss, eng.flat.clone(), ye))
+        res.append((loss, grads, ye))
     monkeypatch.delenv("STDADK_NO_DENSE0_TAIL", raising=False)
+    # same masks on both routes (a mismatch would show at 1e-1 in the loss); GEMM summation order differs
     assert abs(res[0][0] - res[1][0]) <= 2e-6 * max(1.0, abs(res[1][0]))
-    assert rel_l2(res[0][1].cpu().numpy(), res[1][1].cpu().numpy()) <= 2e-6
+    for ga, gb in zip(res[0][1], res[1][1]):
+        assert rel_l2(ga.cpu().numpy(), gb.cpu().numpy()) <= 5e-6
     assert rel_l2(res[0][2].cpu().numpy(), res[1][2].cpu().numpy()) <= 2e-6
 
 
