@@ -345,10 +345,10 @@ def main():
     # ---- N > 1: the configuration BASELINE names for the 8-GPU run (C4: 4 resolutions, 49 728 knots, 12.85 M
     # parameters = a 51 MB gradient) at the per-GPU batch SURVEY.md 8(e) sizes for it (>= 16 384 rows), beside the
     # headline workload above.  Every rank takes part (the step contains the all-reduce).
-    c4_line = None
-    if world > 1 and args.workload != "c4":
-        w4 = WORKLOADS["c4"]
-        B4 = max(16384, B)
+    def weak_line(wname, B4):
+        """One more weak-scaling line at N > 1: workload `wname` at B4 rows per GPU, timed like the headline (barrier +
+        synchronize on both sides, MAX over ranks), plus its all-reduce time.  Every rank takes part."""
+        w4 = WORKLOADS[wname]
         n4 = max(w4["n_obs"] // world, 4 * B4)
         torch.manual_seed(0)
         m4 = STInterpMLP(p=0, k_spatial_centers=w4["k_spatial_centers"], k_temporal_centers=w4["k_temporal_centers"],
@@ -377,11 +377,24 @@ def main():
         torch.cuda.synchronize()
         ar4 = sum(a0.elapsed_time(a1) for a0, a1 in e4.allreduce_events) / max(len(e4.allreduce_events), 1)
         dist.barrier()
-        c4_line = {"workload": w4["name"], "per_gpu_batch": B4, "global_batch": B4 * world, "n_obs_per_gpu": n4,
-                   "obs_per_s": world * B4 * k4 / el4.item(), "ms_per_step": el4.item() / k4 * 1e3, "steps": k4,
-                   "gradient_bytes": 4 * e4.flat.numel(), "allreduce_ms_per_step": ar4, "scaling": "weak",
-                   "dtype": args.dtype}
-        del e4, m4, c4c, c4t, c4y
+        return {"workload": w4["name"], "per_gpu_batch": B4, "global_batch": B4 * world, "n_obs_per_gpu": n4,
+                "obs_per_s": world * B4 * k4 / el4.item(), "ms_per_step": el4.item() / k4 * 1e3, "steps": k4,
+                "gradient_bytes": 4 * e4.flat.numel(), "allreduce_ms_per_step": ar4, "scaling": "weak",
+                "dtype": args.dtype}
+
+    # ---- N > 1: beside the headline line (the reference's batch of 4096 rows per GPU, where the 11 MB gradient
+    # all-reduce is as long as the step), (a) the configuration BASELINE names for the 8-GPU run -- C4: 4 resolutions,
+    # 49 728 knots, 12.85 M parameters = a 51 MB gradient -- at the per-GPU batch SURVEY.md 8(e) sizes for it
+    # (>= 16 384 rows), and (b) the headline model at 65 536 rows per GPU, where the same collective is ~10 % of the step
+    extra_lines = {}
+    if world > 1:
+        for key, wname, bb in (("c4_weak_scaling_line", "c4", max(16384, B)), ("c2_b65536_weak_scaling_line", "c2", 65536)):
+            if wname == args.workload and bb == B:
+                continue
+            try:
+                extra_lines[key] = weak_line(wname, bb)
+            except Exception as e:                      # noqa: BLE001  (the headline line must survive these extras)
+                extra_lines[key] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         recs = N.profile_collect()
         N.profile_enable(False)
@@ -491,8 +504,7 @@ def main():
             # it includes waiting for the slowest rank to arrive)
             out["allreduce"] = {"ms_per_step": allreduce_ms, "gradient_bytes": 4 * P_flat,
                                 "algorithm_bandwidth_GBs": 4 * P_flat / (allreduce_ms * 1e-3) / 1e9 if allreduce_ms else None}
-            if c4_line is not None:
-                out["c4_weak_scaling_line"] = c4_line
+            out.update(extra_lines)
         if args.gpus == 1 and not args.no_sweep:
             def timed(b2, k2, model_kw=None, eng_kw=None, graph=None):
                 """obs/s of the same fused step for another batch size / objective / knot mode."""
