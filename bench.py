@@ -339,6 +339,8 @@ def main():
     allreduce_ms = (sum(e0.elapsed_time(e1) for e0, e1 in eng.allreduce_events) / max(len(eng.allreduce_events), 1)
                     if world > 1 else None)
     eng.allreduce_events = []
+    recs = N.profile_collect() if rank == 0 else None      # the step's launches only: collected before anything else runs
+    N.profile_enable(False)
     if world > 1:
         dist.barrier()
 
@@ -396,8 +398,6 @@ def main():
             except Exception as e:                      # noqa: BLE001  (the headline line must survive these extras)
                 extra_lines[key] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
-        recs = N.profile_collect()
-        N.profile_enable(False)
         agg = {}
         for name, ms in recs:
             a = agg.setdefault(name, [0, 0.0])
