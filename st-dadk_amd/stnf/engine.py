@@ -603,20 +603,24 @@ class TrainStep:
             wsi, prebinned = 1 - pp["last"], False        # not announced: bin inside the step, in place
         if next_idx is not None:
             nxt = next_idx if next_idx.is_contiguous() else next_idx.contiguous()
-            wsj = 1 - wsi
             # the side stream starts after everything enqueued on the main stream so far: the step that last
             # used that workspace (the previous one), AND whatever produced `next_idx` and the resident arrays
             # (a device randperm at the start of an epoch is a multi-kernel sort on the main stream)
             pp["announce"].record(main)
+        # this step's launches go to the main stream BEFORE the side stream's: when the GPU is idle (first step
+        # after a host synchronise) it starts on the step at once instead of after the host has enqueued the
+        # five launches of the next batch's preparation
+        if prebinned:
+            self._enqueue(None, None, None, y_all, B, global_rows, ws=pp["ws"][wsi], prebinned=True)
+        else:
+            self._enqueue(Xa, coords_all, t_all, y_all, B, global_rows, idx=idx, ws=pp["ws"][wsi])
+        if next_idx is not None:
+            wsj = 1 - wsi
             _wait(pp["stream"], pp["announce"])
             with torch.cuda.stream(pp["stream"]):
                 N.bin_batch(st.basis, st.desc, coords_all, t_all, Xa, y_all, nxt, pp["ws"][wsj], st.flags)
                 pp["binned"].record(pp["stream"])
             self._prepared = ((nxt.data_ptr(), nxt.numel()), wsj, nxt)
-        if prebinned:
-            self._enqueue(None, None, None, y_all, B, global_rows, ws=pp["ws"][wsi], prebinned=True)
-        else:
-            self._enqueue(Xa, coords_all, t_all, y_all, B, global_rows, idx=idx, ws=pp["ws"][wsi])
         pp["last"] = wsi
 
     def _step_graph(self, X, coords, t, y, B, global_rows):
