@@ -10,6 +10,8 @@
 
 namespace stdadk {
 
+using T16 = Tail<16>;
+constexpr int TT = T16::TT;
 static_assert(FW_T == TT, "the layer-0 body and the tail bodies must share the workgroup shape");
 
 template <int CPL, bool LN, int BASIS, bool FREE, bool BF>
@@ -28,10 +30,10 @@ __global__ __launch_bounds__(TT) void l1_tail_kernel(L1FwdArgs l, TailFwdArgs f,
   l1_window_fwd_body<CPL, LN, BASIS, FREE>(l, smem, r0, min(r0 + 16, l.B));
   PSTAMP(11);
   __syncthreads();
-  tail_fwd_body<1, false, BF>(f, smem, red, tile);
+  T16::tail_fwd_body<1, false, BF>(f, smem, red, tile);
   PSTAMP(12);
   __syncthreads();
-  tail_bwd_body<1, BF>(b, smem, tile);
+  T16::tail_bwd_body<1, BF>(b, smem, tile);
   PSTAMP(13);
 }
 
@@ -41,7 +43,7 @@ static int launch(const L1FwdArgs &l, const TailFwdArgs &f, const TailBwdArgs &b
   const size_t lds_l1 = ((size_t)l.g.Kt * 64 * CPL + (FW_T / 64) * (LIST * 2 + Kt_pad)) * sizeof(float);
   const size_t lds_fwd = BF ? (size_t)(16 * ACT_LD) * sizeof(float) + (size_t)16 * ABF_LD * sizeof(u16)
                             : (size_t)(2 * 16 * ACT_LD) * sizeof(float);
-  const size_t lds_bwd = tail_bwd_lds_floats<1, BF>() * sizeof(float);
+  const size_t lds_bwd = T16::tail_bwd_lds_floats<1, BF>() * sizeof(float);
   size_t lds = lds_l1 > lds_bwd ? lds_l1 : lds_bwd;
   if (lds_fwd > lds) lds = lds_fwd;
   auto kern = l1_tail_kernel<CPL, LN, BASIS, FREE, BF>;

@@ -11,18 +11,23 @@
 
 namespace stdadk {
 
+// NW: waves per workgroup (tail_body.h): 16 = one 1024-thread workgroup per CU, the only shape the library
+// instantiates; 8 = 512 threads, at most 128 registers and (32-row tiles) 76 KiB of LDS, so that two workgroups share
+// a CU (see TAIL_DISPATCH below).
 // D0: the launch starts from the raw observations (TailDense0 in tail.h); BF: bf16 operands (STDADK_FLAG_BF16)
-template <int MT, bool D0, bool BF>
-__global__ __launch_bounds__(TT) void tail_fwd_kernel(TailFwdArgs a) {
+#define TAIL_BOUNDS(NW) __launch_bounds__(64 * NW, NW == 8 ? 4 : 1)
+
+template <int NW, int MT, bool D0, bool BF>
+__global__ TAIL_BOUNDS(NW) void tail_fwd_kernel(TailFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ float red[TT / 64];
-  tail_fwd_body<MT, D0, BF>(a, smem, red, blockIdx.x);
+  __shared__ float red[NW];
+  Tail<NW>::template tail_fwd_body<MT, D0, BF>(a, smem, red, blockIdx.x);
 }
 
-template <int MT, bool BF>
-__global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
+template <int NW, int MT, bool BF>
+__global__ TAIL_BOUNDS(NW) void tail_bwd_kernel(TailBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  tail_bwd_body<MT, BF>(a, smem, blockIdx.x);
+  Tail<NW>::template tail_bwd_body<MT, BF>(a, smem, blockIdx.x);
 }
 
 // Training step: the forward chain, the loss and the backward chain of a row tile are all row-local, so
@@ -30,13 +35,13 @@ __global__ __launch_bounds__(TT) void tail_bwd_kernel(TailBwdArgs a) {
 // what the forward just wrote in L2).  The forward's global stores (xhat, act, rstd, dY) are complete
 // and visible to the whole workgroup after the __syncthreads() (vmcnt(0) + barrier); none of those lines
 // was read by this CU earlier in the launch, so no stale copy can sit in its L1.
-template <int MT, bool D0, bool BF>
-__global__ __launch_bounds__(TT) void tail_fwd_bwd_kernel(TailFwdArgs f, TailBwdArgs b) {
+template <int NW, int MT, bool D0, bool BF>
+__global__ TAIL_BOUNDS(NW) void tail_fwd_bwd_kernel(TailFwdArgs f, TailBwdArgs b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ float red[TT / 64];
-  tail_fwd_body<MT, D0, BF>(f, smem, red, blockIdx.x);
+  __shared__ float red[NW];
+  Tail<NW>::template tail_fwd_body<MT, D0, BF>(f, smem, red, blockIdx.x);
   __syncthreads();
-  tail_bwd_body<MT, BF>(b, smem, blockIdx.x);
+  Tail<NW>::template tail_bwd_body<MT, BF>(b, smem, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -53,12 +58,13 @@ static size_t fwd_lds(int R, bool d0, bool bf) {
   if (!bf) return (size_t)(2 * R * ACT_LD) * sizeof(float);
   return (size_t)((d0 ? 2 : 1) * R * ACT_LD) * sizeof(float) + (size_t)R * ABF_LD * sizeof(u16);
 }
+template <int NW>
 static size_t bwd_lds(int R, bool bf) {
-  if (bf) return (R == 64 ? tail_bwd_lds_floats<4, true>() : (R == 32 ? tail_bwd_lds_floats<2, true>() : tail_bwd_lds_floats<1, true>())) * sizeof(float);
-  return (R == 64 ? tail_bwd_lds_floats<4, false>() : (R == 32 ? tail_bwd_lds_floats<2, false>() : tail_bwd_lds_floats<1, false>())) * sizeof(float);
+  using T = Tail<NW>;
+  if (bf) return (R == 64 ? T::template tail_bwd_lds_floats<4, true>() : (R == 32 ? T::template tail_bwd_lds_floats<2, true>() : T::template tail_bwd_lds_floats<1, true>())) * sizeof(float);
+  return (R == 64 ? T::template tail_bwd_lds_floats<4, false>() : (R == 32 ? T::template tail_bwd_lds_floats<2, false>() : T::template tail_bwd_lds_floats<1, false>())) * sizeof(float);
 }
-static_assert(tail_bwd_lds_floats<4, true>() * sizeof(float) <= 160 * 1024, "bf16 backward tile does not fit the LDS");
-
+static_assert(Tail<16>::tail_bwd_lds_floats<4, true>() * sizeof(float) <= 160 * 1024, "bf16 backward tile does not fit the LDS");
 int tail_rows(int64_t B, bool cap32) {
   // two or four 16-row tiles per workgroup (shared weight fragments) once that still gives every CU
   // a workgroup; one tile per workgroup for small batches
@@ -95,31 +101,35 @@ static int check_d0(const TailFwdArgs &a) {
   return 0;
 }
 
-template <int MT, bool D0, bool BF>
+template <int NW, int MT, bool D0, bool BF>
 static int launch_fwd(const TailFwdArgs &a, hipStream_t st) {
-  constexpr int R = 16 * MT;
+  constexpr int R = 16 * MT, TT = 64 * NW;
   static bool attr_done = false;
   if (!attr_done) {   // once per process, never inside a stream capture (the first step runs eagerly)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel<MT, D0, BF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel<NW, MT, D0, BF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds(R, D0, BF));
     if (e != hipSuccess) { set_error("tail_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
   STDADK_LAUNCH_NAMED(D0 ? (BF ? "tail_fwd_kernel<dense0,bf16>" : "tail_fwd_kernel<dense0>") : (BF ? "tail_fwd_kernel<bf16>" : "tail_fwd_kernel"),
-                      (tail_fwd_kernel<MT, D0, BF>), dim3((unsigned)ceil_div(a.B, R)), dim3(TT), fwd_lds(R, D0, BF), st, a);
+                      (tail_fwd_kernel<NW, MT, D0, BF>), dim3((unsigned)ceil_div(a.B, R)), dim3(TT), fwd_lds(R, D0, BF), st, a);
   STDADK_CHECK_LAUNCH("tail_forward");
   return 0;
 }
 
-// dispatch on (rows, dense layer 0, bf16 operands); the bf16 + dense-0 combination is built for <= 32 rows
+// dispatch on (rows, dense layer 0, bf16 operands); the bf16 + dense-0 combination is built for <= 32 rows.
+// All launches use Tail<16> (1024 threads, one workgroup per CU): Tail<8> -- 512 threads, 32-row tiles, TWO
+// workgroups per CU (confirmed by tools/diag/occupancy_tail8.hip), meant to overlap one tile's row-local phases with
+// the other's GEMM phases -- measured 0-4 % SLOWER at 16 384 and 65 536 rows, fp32 and bf16, so
+// it is not instantiated in the library.
 #define TAIL_DISPATCH(FN, r, d0, bf, ...)                                                                    \
-  ((bf) ? ((d0) ? ((r) == 32 ? FN<2, true, true>(__VA_ARGS__) : FN<1, true, true>(__VA_ARGS__))              \
-                : ((r) == 64 ? FN<4, false, true>(__VA_ARGS__)                                               \
-                             : ((r) == 32 ? FN<2, false, true>(__VA_ARGS__) : FN<1, false, true>(__VA_ARGS__)))) \
-        : ((d0) ? ((r) == 64 ? FN<4, true, false>(__VA_ARGS__)                                               \
-                             : ((r) == 32 ? FN<2, true, false>(__VA_ARGS__) : FN<1, true, false>(__VA_ARGS__))) \
-                : ((r) == 64 ? FN<4, false, false>(__VA_ARGS__)                                              \
-                             : ((r) == 32 ? FN<2, false, false>(__VA_ARGS__) : FN<1, false, false>(__VA_ARGS__)))))
+  ((bf) ? ((d0) ? ((r) == 32 ? FN<16, 2, true, true>(__VA_ARGS__) : FN<16, 1, true, true>(__VA_ARGS__))      \
+                : ((r) == 64 ? FN<16, 4, false, true>(__VA_ARGS__)                                           \
+                             : ((r) == 32 ? FN<16, 2, false, true>(__VA_ARGS__) : FN<16, 1, false, true>(__VA_ARGS__)))) \
+        : ((d0) ? ((r) == 64 ? FN<16, 4, true, false>(__VA_ARGS__)                                           \
+                             : ((r) == 32 ? FN<16, 2, true, false>(__VA_ARGS__) : FN<16, 1, true, false>(__VA_ARGS__))) \
+                : ((r) == 64 ? FN<16, 4, false, false>(__VA_ARGS__)                                          \
+                             : ((r) == 32 ? FN<16, 2, false, false>(__VA_ARGS__) : FN<16, 1, false, false>(__VA_ARGS__)))))
 
 int tail_forward(const TailFwdArgs &a, hipStream_t st) {
   const bool d0 = a.d0.on != 0, bf = a.bf16 != 0;
@@ -129,36 +139,36 @@ int tail_forward(const TailFwdArgs &a, hipStream_t st) {
   return TAIL_DISPATCH(launch_fwd, r, d0, bf, a, st);
 }
 
-template <int MT, bool BF>
+template <int NW, int MT, bool BF>
 static int launch_bwd(const TailBwdArgs &a, hipStream_t st) {
-  constexpr int R = 16 * MT;
+  constexpr int R = 16 * MT, TT = 64 * NW;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel<MT, BF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds(R, BF));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel<NW, MT, BF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<NW>(R, BF));
     if (e != hipSuccess) { set_error("tail_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  STDADK_LAUNCH_NAMED(BF ? "tail_bwd_kernel<bf16>" : "tail_bwd_kernel", (tail_bwd_kernel<MT, BF>),
-                      dim3((unsigned)ceil_div(a.B, R)), dim3(TT), bwd_lds(R, BF), st, a);
+  STDADK_LAUNCH_NAMED(BF ? "tail_bwd_kernel<bf16>" : "tail_bwd_kernel", (tail_bwd_kernel<NW, MT, BF>),
+                      dim3((unsigned)ceil_div(a.B, R)), dim3(TT), bwd_lds<NW>(R, BF), st, a);
   STDADK_CHECK_LAUNCH("tail_backward");
   return 0;
 }
 
-template <int MT, bool D0, bool BF>
+template <int NW, int MT, bool D0, bool BF>
 static int launch_fwd_bwd(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_t st) {
-  constexpr int R = 16 * MT;
-  const size_t lds = fwd_lds(R, D0, BF) > bwd_lds(R, BF) ? fwd_lds(R, D0, BF) : bwd_lds(R, BF);
+  constexpr int R = 16 * MT, TT = 64 * NW;
+  const size_t lds = fwd_lds(R, D0, BF) > bwd_lds<NW>(R, BF) ? fwd_lds(R, D0, BF) : bwd_lds<NW>(R, BF);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_bwd_kernel<MT, D0, BF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_bwd_kernel<NW, MT, D0, BF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("tail_forward_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
   STDADK_LAUNCH_NAMED(D0 ? (BF ? "tail_fwd_bwd_kernel<dense0,bf16>" : "tail_fwd_bwd_kernel<dense0>")
                          : (BF ? "tail_fwd_bwd_kernel<bf16>" : "tail_fwd_bwd_kernel"),
-                      (tail_fwd_bwd_kernel<MT, D0, BF>), dim3((unsigned)ceil_div(f.B, R)), dim3(TT), lds, st, f, b);
+                      (tail_fwd_bwd_kernel<NW, MT, D0, BF>), dim3((unsigned)ceil_div(f.B, R)), dim3(TT), lds, st, f, b);
   STDADK_CHECK_LAUNCH("tail_forward_backward");
   return 0;
 }
@@ -178,8 +188,8 @@ int tail_forward_backward(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_
 int tail_backward(const TailBwdArgs &a, hipStream_t st, bool cap32) {
   const int r = tail_rows(a.B, cap32);
   if (int rc = check_bf(a.bf16, a.n_layers, a.L, false, 1)) return rc;
-  if (a.bf16) return r == 64 ? launch_bwd<4, true>(a, st) : (r == 32 ? launch_bwd<2, true>(a, st) : launch_bwd<1, true>(a, st));
-  return r == 64 ? launch_bwd<4, false>(a, st) : (r == 32 ? launch_bwd<2, false>(a, st) : launch_bwd<1, false>(a, st));
+  if (a.bf16) return r == 64 ? launch_bwd<16, 4, true>(a, st) : (r == 32 ? launch_bwd<16, 2, true>(a, st) : launch_bwd<16, 1, true>(a, st));
+  return r == 64 ? launch_bwd<16, 4, false>(a, st) : (r == 32 ? launch_bwd<16, 2, false>(a, st) : launch_bwd<16, 1, false>(a, st));
 }
 
 }  // namespace stdadk

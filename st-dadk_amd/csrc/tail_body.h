@@ -1,5 +1,14 @@
 // Bodies of the fused MLP-tail kernels (see tail.h / tail.hip), shared by their own kernels and by the
 // fused training-step kernel (fused_step.hip).  `tile` = index of the row tile (R rows) a workgroup carries.
+//
+// Everything that depends on the workgroup shape lives in Tail<NW> (NW waves of 64 lanes):
+//   Tail<16>: 1024 threads, ONE workgroup per CU, one 16-column N tile per wave; 16 / 32 / 64-row tiles.  The shape of
+//             every launch of the library and of the fused step kernel (fused_step.hip) -- at 16 rows per CU the
+//             phases are latency-bound and more waves = more loads in flight.
+//   Tail<8>:  512 threads, up to two N tiles per wave, 32-row tiles whose LDS (<= 76 KiB) and registers (<= 128) let
+//             TWO workgroups share a CU, so that one's row-local phases (LayerNorm, stores, barriers) could run beside
+//             the other's GEMM phases.  Built, parity-tested and measured in round 2: no faster at any batch size
+//             (DESIGN.md section 8), so the library does not instantiate it; tools/diag/occupancy_tail8.hip does.
 #pragma once
 #include "tail.h"
 #include "basis.h"
@@ -8,10 +17,6 @@ namespace stdadk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NW = 16;                        // waves per workgroup (4 per SIMD): the phases are latency-bound at
-                                              // 16 rows per workgroup, more waves = more loads in flight
-constexpr int TT = 64 * NW;                   // threads per workgroup
-constexpr int MAX_NI = TAIL_MAX_W / 16 / NW;  // N tiles per wave
 constexpr int ACT_LD = TAIL_MAX_W + 4;        // activation row stride in LDS (floats)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
@@ -24,102 +29,8 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-
 template <int NI>
-struct BFrag { float4 v[2 * NI]; };     // [j*NI + i] : chunk fragment of this lane
-
-// Loads are UNCONDITIONAL from clamped (always valid) addresses and never masked in registers: a
-// conditional load gets its own branch + vmcnt(0), and a select on the loaded value drags the wait
-// in front of the MFMAs of the previous chunk.  The number of N tiles of this wave (NI) is a
-// template parameter and the K-half test is scalar, so the MFMA stream has no exec-masked branches.
-template <int NI>
-__device__ __forceinline__ void load_bfrag(BFrag<NI> &f, const float *__restrict__ Wn, int K, int c, int wave,
-                                           int c16, int q) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int k = 32 * c + 16 * j + 4 * q;
-    const int kc = k < K ? k : 0;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int n = 16 * (wave + NW * i) + c16;         // < N by construction of NI
-      f.v[j * NI + i] = *reinterpret_cast<const float4 *>(Wn + (size_t)n * K + kc);
-    }
-  }
-}
-
-// Same fragment from a [K][N] row-major operand (N contiguous): nn.Linear's own (out,in) weight read as
-// the B operand of dA = dZ . W — four dword loads (64-byte pieces per 16 lanes) instead of one dwordx4,
-// and no transposed copy of the weights is needed.  Component e of v[j] is k = 32c + 16j + 4q + e, the
-// same k order as the A fragments, so the MFMA stream is unchanged.
-__device__ __forceinline__ void load_bfrag_kn(BFrag<1> &f, const float *__restrict__ Wkn, int N, int K, int c, int wave,
-                                              int c16, int q) {
-  const int n = 16 * wave + c16;                      // < N by the caller's wave < N/16 test
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int k = 32 * c + 16 * j + 4 * q;
-    const int kc = k < K ? k : 0;
-    const float *b = Wkn + (size_t)kc * N + n;
-    f.v[j] = make_float4(b[0], b[N], b[2 * (size_t)N], b[3 * (size_t)N]);
-  }
-}
-
-template <int NI, int MT>
-__device__ __forceinline__ void mma_chunk(f32x4 (*acc)[MAX_NI], const BFrag<NI> &f, const float *__restrict__ A, int K,
-                                          int c, int c16, int q) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if (32 * c + 16 * j < K) {          // scalar: K is a multiple of 16, a 16-deep half is all in or out
-      float af[MT][4];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float4 av = *reinterpret_cast<const float4 *>(A + (16 * mt + c16) * ACT_LD + 32 * c + 16 * j + 4 * q);
-        af[mt][0] = av.x; af[mt][1] = av.y; af[mt][2] = av.z; af[mt][3] = av.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const float4 bv = f.v[j * NI + i];
-          const float bf[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {    // every weight fragment feeds both row tiles
-            acc[mt][i] = mfma16(af[mt][e], bf[e], acc[mt][i]);
-          }
-        }
-      }
-    }
-  }
-}
-
-// The first 32-deep weight chunk of a GEMM phase, requested one phase EARLY (before the row-local
-// LayerNorm / input phase that precedes the GEMM) so that its L2 round trip is hidden behind that phase.
-static_assert(MAX_NI == 1, "the preloaded variant below assumes one N tile per wave");
-__device__ __forceinline__ void preload_w(BFrag<1> &f, const float *__restrict__ Wn, int N, int K, int wave, int c16,
-                                          int q) {
-  if (wave < (N >> 4)) load_bfrag<1>(f, Wn, K, 0, wave, c16, q);
-}
-
-// gemm16 with chunk 0 already in registers (see preload_w).  KN: the weight operand is [K][N] row-major.
-template <int MT, bool KN = false>
-__device__ __forceinline__ void gemm16_pre(f32x4 (*acc)[MAX_NI], const float *__restrict__ A, const float *__restrict__ Wn,
-                                           int N, int K, int wave, int c16, int q, BFrag<1> &f0) {
-  if (wave >= (N >> 4)) return;                 // scalar: this wave has no N tile in a narrow layer
-  const int nchunk = (K + 31) >> 5;
-  BFrag<1> f1;
-  for (int c = 0; c < nchunk; c += 2) {
-    if (c + 1 < nchunk) { if (KN) load_bfrag_kn(f1, Wn, N, K, c + 1, wave, c16, q); else load_bfrag<1>(f1, Wn, K, c + 1, wave, c16, q); }
-    mma_chunk<1, MT>(acc, f0, A, K, c, c16, q);
-    if (c + 1 < nchunk) {
-      if (c + 2 < nchunk) { if (KN) load_bfrag_kn(f0, Wn, N, K, c + 2, wave, c16, q); else load_bfrag<1>(f0, Wn, K, c + 2, wave, c16, q); }
-      mma_chunk<1, MT>(acc, f1, A, K, c + 1, c16, q);
-    }
-  }
-}
-
-__device__ __forceinline__ void preload_w_kn(BFrag<1> &f, const float *__restrict__ Wkn, int N, int K, int wave, int c16,
-                                             int q) {
-  if (wave < (N >> 4)) load_bfrag_kn(f, Wkn, N, K, 0, wave, c16, q);
-}
+struct BFrag { float4 v[2 * NI]; };     // [2*i + j]: chunk fragment of this lane, N tile i, 16-deep half j
 
 // ---------------------------------------------------------------------------------------------
 // bf16 operands (STDADK_FLAG_BF16): v_mfma_f32_16x16x32_bf16, fp32 accumulate
@@ -143,53 +54,180 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 }
 __device__ __forceinline__ u16 to_bf16(float a) { return (u16)(pack_bf16(a, 0.f) & 0xffffu); }
 
-struct BFragH { uint4 v[2]; };          // this lane's 16 k of weight row n in chunk c
+template <int NI>
+struct BFragH { uint4 v[2 * NI]; };     // [2*i + half]: this lane's 16 k of weight row n_i in chunk c
 
-// unconditional loads from clamped addresses like load_bfrag; a piece beyond K meets zeros in the A image
-__device__ __forceinline__ void load_bfrag_h(BFragH &f, const u16 *__restrict__ Wn, int K, int c, int wave, int c16, int q) {
-  const int n = 16 * wave + c16;                      // < N by the caller's wave < N/16 test
-  const int k = 64 * c + 16 * q;
-  const uint4 *src = reinterpret_cast<const uint4 *>(Wn + (size_t)n * K + (k < K ? k : 0));
-  f.v[0] = src[0]; f.v[1] = src[1];
-}
+#ifdef STDADK_DIAG   // diagnostic build only: in-kernel wall-clock stamps of the phases
+#define STAMP(i) do { if (a.stamps && tid == 0) a.stamps[tile * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
-template <int MT>
-__device__ __forceinline__ void mma_chunk_h(f32x4 (*acc)[MAX_NI], const BFragH &f, const u16 *__restrict__ A, int c, int c16,
-                                            int q) {
+template <int NW_>
+struct Tail {
+static constexpr int NW = NW_;                       // waves per workgroup
+static constexpr int TT = 64 * NW;                   // threads per workgroup
+static constexpr int MAX_NI = TAIL_MAX_W / 16 / NW;  // N tiles per wave: tile i of a wave is column tile wave + NW*i
+static_assert(MAX_NI == 1 || MAX_NI == 2, "Tail<NW>: 8 or 16 waves");
+
+// N tiles per wave a GEMM of width N runs with (scalar).  A tile index beyond the layer's N/16 tiles (widths that
+// are not a multiple of 16*NW) is clamped for the loads and its accumulator is never stored.
+static __device__ __forceinline__ int tiles_of(int N) { return ((N >> 4) + NW - 1) / NW; }
+
+// Loads are UNCONDITIONAL from clamped (always valid) addresses and never masked in registers: a
+// conditional load gets its own branch + vmcnt(0), and a select on the loaded value drags the wait
+// in front of the MFMAs of the previous chunk.  The number of N tiles of this wave (NI) is a
+// template parameter and the K-half test is scalar, so the MFMA stream has no exec-masked branches.
+// KN = false: W is [N][K] (K contiguous): one dwordx4 per tile and 16-deep half.
+// KN = true:  W is [K][N] row-major (N contiguous): nn.Linear's own (out,in) weight read as the B operand of
+//             dA = dZ . W -- four dword loads (64-byte pieces per 16 lanes) instead of one dwordx4, and no
+//             transposed copy of the weights is needed.  Component e of v[..] is k = 32c + 16j + 4q + e in both
+//             forms, the same k order as the A fragments.
+template <int NI, bool KN>
+static __device__ __forceinline__ void load_bfrag(BFrag<MAX_NI> &f, const float *__restrict__ W, int N, int K, int c,
+                                                  int wave, int c16, int q) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const uint4 *ap = reinterpret_cast<const uint4 *>(A + (16 * mt + c16) * ABF_LD + 64 * c + 16 * q);
-    const uint4 a0 = ap[0], a1 = ap[1];
-    acc[mt][0] = mfma16h(a0, f.v[0], acc[mt][0]);
-    acc[mt][0] = mfma16h(a1, f.v[1], acc[mt][0]);
-  }
-}
-
-__device__ __forceinline__ void preload_wh(BFragH &f, const u16 *__restrict__ Wn, int N, int K, int wave, int c16, int q) {
-  if (wave < (N >> 4)) load_bfrag_h(f, Wn, K, 0, wave, c16, q);
-}
-
-// acc[mt][0] += A[R x K] (bf16 image in LDS, columns K .. 64 ceil(K/64) zero) * W^T, W = [N][K] bf16 in global
-// memory, chunk 0 already in registers (preload_wh), two chunks in flight
-template <int MT>
-__device__ __forceinline__ void gemm16_pre_h(f32x4 (*acc)[MAX_NI], const u16 *__restrict__ A, const u16 *__restrict__ Wn,
-                                             int N, int K, int wave, int c16, int q, BFragH &f0) {
-  if (wave >= (N >> 4)) return;
-  const int nchunk = (K + 63) >> 6;
-  BFragH f1;
-  for (int c = 0; c < nchunk; c += 2) {
-    if (c + 1 < nchunk) load_bfrag_h(f1, Wn, K, c + 1, wave, c16, q);
-    mma_chunk_h<MT>(acc, f0, A, c, c16, q);
-    if (c + 1 < nchunk) {
-      if (c + 2 < nchunk) load_bfrag_h(f0, Wn, K, c + 2, wave, c16, q);
-      mma_chunk_h<MT>(acc, f1, A, c + 1, c16, q);
+  for (int j = 0; j < 2; ++j) {
+    const int k = 32 * c + 16 * j + 4 * q;
+    const int kc = k < K ? k : 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = min(16 * (wave + NW * i), N - 16) + c16;
+      if constexpr (KN) {
+        const float *b = W + (size_t)kc * N + n;
+        f.v[2 * i + j] = make_float4(b[0], b[N], b[2 * (size_t)N], b[3 * (size_t)N]);
+      } else {
+        f.v[2 * i + j] = *reinterpret_cast<const float4 *>(W + (size_t)n * K + kc);
+      }
     }
   }
 }
 
-// GEMM of a phase: acc[mt][0] (rows 16 mt.., N tile of this wave) += A[R x K] (LDS, row stride ACT_LD) * W.
+template <int NI, int MT>
+static __device__ __forceinline__ void mma_chunk(f32x4 (*acc)[MAX_NI], const BFrag<MAX_NI> &f, const float *__restrict__ A,
+                                                 int K, int c, int c16, int q) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (32 * c + 16 * j < K) {          // scalar: K is a multiple of 16, a 16-deep half is all in or out
+      float af[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 av = *reinterpret_cast<const float4 *>(A + (16 * mt + c16) * ACT_LD + 32 * c + 16 * j + 4 * q);
+        af[mt][0] = av.x; af[mt][1] = av.y; af[mt][2] = av.z; af[mt][3] = av.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const float4 bv = f.v[2 * i + j];
+          const float bf[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {    // every weight fragment feeds all row tiles
+            acc[mt][i] = mfma16(af[mt][e], bf[e], acc[mt][i]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// The first 32-deep weight chunk of a GEMM phase, requested one phase EARLY (before the row-local
+// LayerNorm / input phase that precedes the GEMM) so that its L2 round trip is hidden behind that phase.
+template <bool KN = false>
+static __device__ __forceinline__ void preload_w(BFrag<MAX_NI> &f, const float *__restrict__ W, int N, int K,
+                                                 int wave, int c16, int q) {
+  // always all MAX_NI tiles (a tile the layer does not have is a clamped, unused load): one write pattern for the
+  // fragment whatever the layer's width keeps it in registers
+  if (wave < (N >> 4)) load_bfrag<MAX_NI, KN>(f, W, N, K, 0, wave, c16, q);
+}
+
+// GEMM of a phase: acc[mt][i] (rows 16 mt.., N tile wave + NW*i) += A[R x K] (LDS, row stride ACT_LD) * W.
 // M = 16..64 rows is the GEMV-like regime: every wave streams ITS OWN slice of W straight into VGPRs (no
-// LDS staging, no workgroup barrier in the K loop), two 32-deep chunks in flight.
+// LDS staging, no workgroup barrier in the K loop), two 32-deep chunks in flight; chunk 0 is already in
+// registers (preload_w).
+template <int MT, int NI, bool KN>
+static __device__ __forceinline__ void gemm16_loop(f32x4 (*acc)[MAX_NI], const float *__restrict__ A,
+                                                   const float *__restrict__ W, int N, int K, int wave, int c16,
+                                                   int q, BFrag<MAX_NI> &f0) {
+  const int nchunk = (K + 31) >> 5;
+  BFrag<MAX_NI> f1;
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 1 < nchunk) load_bfrag<NI, KN>(f1, W, N, K, c + 1, wave, c16, q);
+    mma_chunk<NI, MT>(acc, f0, A, K, c, c16, q);
+    if (c + 1 < nchunk) {
+      if (c + 2 < nchunk) load_bfrag<NI, KN>(f0, W, N, K, c + 2, wave, c16, q);
+      mma_chunk<NI, MT>(acc, f1, A, K, c + 1, c16, q);
+    }
+  }
+}
+template <int MT, bool KN = false>
+static __device__ __forceinline__ void gemm16_pre(f32x4 (*acc)[MAX_NI], const float *__restrict__ A,
+                                                  const float *__restrict__ W, int N, int K, int wave, int c16,
+                                                  int q, BFrag<MAX_NI> &f0) {
+  if (wave >= (N >> 4)) return;                 // scalar: this wave has no N tile in a narrow layer
+  if (MAX_NI > 1 && tiles_of(N) > 1) gemm16_loop<MT, MAX_NI, KN>(acc, A, W, N, K, wave, c16, q, f0);
+  else gemm16_loop<MT, 1, KN>(acc, A, W, N, K, wave, c16, q, f0);
+}
+
+// ---- bf16 operands
+// unconditional loads from clamped addresses like load_bfrag; a piece beyond K meets zeros in the A image
+template <int NI>
+static __device__ __forceinline__ void load_bfrag_h(BFragH<MAX_NI> &f, const u16 *__restrict__ Wn, int N, int K, int c,
+                                                    int wave, int c16, int q) {
+  const int k = 64 * c + 16 * q;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int n = min(16 * (wave + NW * i), N - 16) + c16;
+    const uint4 *src = reinterpret_cast<const uint4 *>(Wn + (size_t)n * K + (k < K ? k : 0));
+    f.v[2 * i] = src[0]; f.v[2 * i + 1] = src[1];
+  }
+}
+
+template <int NI, int MT>
+static __device__ __forceinline__ void mma_chunk_h(f32x4 (*acc)[MAX_NI], const BFragH<MAX_NI> &f, const u16 *__restrict__ A,
+                                                   int c, int c16, int q) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const uint4 *ap = reinterpret_cast<const uint4 *>(A + (16 * mt + c16) * ABF_LD + 64 * c + 16 * q);
+    const uint4 a0 = ap[0], a1 = ap[1];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      acc[mt][i] = mfma16h(a0, f.v[2 * i], acc[mt][i]);
+      acc[mt][i] = mfma16h(a1, f.v[2 * i + 1], acc[mt][i]);
+    }
+  }
+}
+
+static __device__ __forceinline__ void preload_wh(BFragH<MAX_NI> &f, const u16 *__restrict__ Wn, int N, int K, int wave,
+                                                  int c16, int q) {
+  if (wave < (N >> 4)) load_bfrag_h<MAX_NI>(f, Wn, N, K, 0, wave, c16, q);
+}
+
+// acc[mt][i] += A[R x K] (bf16 image in LDS, columns K .. 64 ceil(K/64) zero) * W^T, W = [N][K] bf16 in global
+// memory, chunk 0 already in registers (preload_wh), two chunks in flight
+template <int MT, int NI>
+static __device__ __forceinline__ void gemm16_loop_h(f32x4 (*acc)[MAX_NI], const u16 *__restrict__ A,
+                                                     const u16 *__restrict__ Wn, int N, int K, int wave, int c16, int q,
+                                                     BFragH<MAX_NI> &f0) {
+  const int nchunk = (K + 63) >> 6;
+  BFragH<MAX_NI> f1;
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 1 < nchunk) load_bfrag_h<NI>(f1, Wn, N, K, c + 1, wave, c16, q);
+    mma_chunk_h<NI, MT>(acc, f0, A, c, c16, q);
+    if (c + 1 < nchunk) {
+      if (c + 2 < nchunk) load_bfrag_h<NI>(f0, Wn, N, K, c + 2, wave, c16, q);
+      mma_chunk_h<NI, MT>(acc, f1, A, c + 1, c16, q);
+    }
+  }
+}
+template <int MT>
+static __device__ __forceinline__ void gemm16_pre_h(f32x4 (*acc)[MAX_NI], const u16 *__restrict__ A,
+                                                    const u16 *__restrict__ Wn, int N, int K, int wave, int c16, int q,
+                                                    BFragH<MAX_NI> &f0) {
+  if (wave >= (N >> 4)) return;
+  if (MAX_NI > 1 && tiles_of(N) > 1) gemm16_loop_h<MT, MAX_NI>(acc, A, Wn, N, K, wave, c16, q, f0);
+  else gemm16_loop_h<MT, 1>(acc, A, Wn, N, K, wave, c16, q, f0);
+}
 
 // ---------------------------------------------------------------------------------------------
 // layer 0 from the raw observations (TailDense0)
@@ -198,7 +236,7 @@ __device__ __forceinline__ void gemm16_pre_h(f32x4 (*acc)[MAX_NI], const u16 *__
 // D; and into the feature buffer (row stride ldf = D rounded up to 32, padding zero) for the backward.
 // Same arithmetic as rbf_build_kernel (phi_eval / psi_eval of basis.h).
 template <int MT>
-__device__ __forceinline__ void d0_fill_features(const TailDense0 &z, float *act0, float *act1, int row0, int B) {
+static __device__ __forceinline__ void d0_fill_features(const TailDense0 &z, float *act0, float *act1, int row0, int B) {
   constexpr int R = 16 * MT;
   const int D = z.p + z.Ks + z.Kt;
   const int Dp = (D + 31) & ~31;
@@ -228,7 +266,7 @@ __device__ __forceinline__ void d0_fill_features(const TailDense0 &z, float *act
 }
 
 // B fragment of chunk c from W0^T [D][N] with every row index clamped below D (the A columns there are zero)
-__device__ __forceinline__ void d0_load_bfrag(BFrag<1> &f, const float *__restrict__ W0T, int N, int D, int c, int wave,
+static __device__ __forceinline__ void d0_load_bfrag(BFrag<MAX_NI> &f, const float *__restrict__ W0T, int N, int D, int c, int wave,
                                               int c16, int q) {
   const int n = 16 * wave + c16;
 #pragma unroll
@@ -242,14 +280,15 @@ __device__ __forceinline__ void d0_load_bfrag(BFrag<1> &f, const float *__restri
 
 // acc += features (LDS, two 256-column halves) . W0^T, 32-deep chunks, two in flight like gemm16_pre
 template <int MT>
-__device__ __forceinline__ void d0_gemm(f32x4 (*acc)[MAX_NI], const float *act0, const float *act1,
-                                        const float *__restrict__ W0T, int N, int D, int wave, int c16, int q,
-                                        BFrag<1> &f0) {
+static __device__ __forceinline__ void d0_gemm(f32x4 (*acc)[MAX_NI], const float *act0, const float *act1,
+                                               const float *__restrict__ W0T, int N, int D, int wave, int c16, int q,
+                                               BFrag<MAX_NI> &f0) {
+  static_assert(MAX_NI == 1, "the dense layer 0 inside the tail launch is built for 16 waves");
   if (wave >= (N >> 4)) return;
   const int Kp = (D + 15) & ~15;                 // mma_chunk works in 16-deep halves
   const int nchunk = (D + 31) >> 5;
   constexpr int HC = TAIL_MAX_W / 32;            // chunks per LDS half
-  BFrag<1> f1;
+  BFrag<MAX_NI> f1;
   for (int c = 0; c < nchunk; c += 2) {
     if (c + 1 < nchunk) d0_load_bfrag(f1, W0T, N, D, c + 1, wave, c16, q);
     mma_chunk<1, MT>(acc, f0, c < HC ? act0 : act1 - TAIL_MAX_W, Kp, c, c16, q);
@@ -263,17 +302,12 @@ __device__ __forceinline__ void d0_gemm(f32x4 (*acc)[MAX_NI], const float *act0,
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-#ifdef STDADK_DIAG   // diagnostic build only: in-kernel wall-clock stamps of the phases
-#define STAMP(i) do { if (a.stamps && tid == 0) a.stamps[tile * 16 + (i)] = wall_clock64(); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
 // BF: the layers' GEMMs take bf16 operands (fp32 accumulate; LayerNorm, loss and everything kept for the backward
 // stay fp32).  LDS then holds ONE fp32 tile (z / LayerNorm in place; the head reads it) and the bf16 image of the
 // current activations in the place of the second fp32 tile -- with D0 the fp32 pair stays (the features of layer 0
 // use both halves) and the image follows them.
 template <int MT, bool D0 = false, bool BF = false>
-__device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem, float *red, const int tile) {
+static __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem, float *red, const int tile) {
   constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
   float *act0 = smem, *act1 = (BF && !D0) ? smem : smem + R * ACT_LD;
   u16 *abf = reinterpret_cast<u16 *>(smem + (D0 ? 2 : 1) * R * ACT_LD);
@@ -282,8 +316,9 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = tile * R;
   STAMP(0);
-  BFrag<1> wpre;
-  BFragH wpre_h;
+  static_assert(!D0 || MAX_NI == 1, "the dense layer 0 inside the tail launch is built for 16 waves");
+  BFrag<MAX_NI> wpre;
+  BFragH<MAX_NI> wpre_h;
   if constexpr (D0) {
     if (a.d0.on == 1) {
       if (wave < (a.d0.L0.h >> 4)) d0_load_bfrag(wpre, a.d0.W0T, a.d0.L0.h, a.d0.L0.hp, 0, wave, c16, q);
@@ -330,6 +365,7 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const uint32_t drop_thr = drop_threshold(a.drop_p);
+  const bool drop_on = a.drop_p > 0.f, ln_on = a.layernorm != 0;      // scalar
   float *cur = act0, *nxt = act1;
   STAMP(1);
   // output-layer weights of q = 0 (the MSE head has Q = 1): requested now, used at the very end
@@ -372,8 +408,10 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
             make_float4((u.x + w.x) + bb.x, (u.y + w.y) + bb.y, (u.z + w.z) + bb.z, (u.w + w.w) + bb.w);
       }
     } else if (D0 && li < 0) {
-      d0_gemm<MT>(acc, act0, act1, a.d0.W0T, h, hp, wave, c16, q, wpre);
-      if (hp > TAIL_MAX_W) lds_barrier();        // z goes into act1, which held the second half of the features
+      if constexpr (D0) {
+        d0_gemm<MT>(acc, act0, act1, a.d0.W0T, h, hp, wave, c16, q, wpre);
+        if (hp > TAIL_MAX_W) lds_barrier();      // z goes into act1, which held the second half of the features
+      }
     } else {
       if constexpr (BF) gemm16_pre_h<MT>(acc, abf, L.Wbf, h, hp, wave, c16, q, wpre_h);
       else gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre);
@@ -398,50 +436,79 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
     }
     lds_barrier();
     STAMP(3 + 4 * (li < 0 ? 0 : li));
-    // LayerNorm -> ReLU -> Dropout, wave w owns rows RPW*w .. RPW*w+RPW-1
+    // LayerNorm -> ReLU -> Dropout, wave w owns rows RPW*w .. RPW*w+RPW-1.  Written as stages over the wave's rows:
+    // everything the phase needs from the argument block is in registers before its first store (the stores are
+    // conditional, and the compiler otherwise fetches the pointers under each condition: a scalar load + wait per
+    // element); the rows' two reductions are independent chains; a row's stores go out together.  Same arithmetic,
+    // in the same order, as a row at a time.
+    {
+      float *const xhat_p = L.xhat, *const act_p = L.act, *const rstd_p = L.rstd;     // NULL in eval mode
+      const int lid = L.layer_id;
+      bool okc[4];
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int row = RPW * wave + rr;
-      const int grow = row0 + row;
-      float z[4];
-      float s = 0.f;
+      for (int cc = 0; cc < 4; ++cc) okc[cc] = lane + 64 * cc < h;
+      float z[RPW][4], mean[RPW], rs[RPW];
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int col = lane + 64 * cc;
-        z[cc] = col < h ? nxt[row * ACT_LD + col] : 0.f;
-        s += z[cc];
-      }
-      float mean = 0.f, rs = 1.f;
-      if (a.layernorm) {
-        mean = wave_sum(s) / (float)h;
-        float sq = 0.f;
+      for (int rr = 0; rr < RPW; ++rr) {
+        const float *zp = nxt + (RPW * wave + rr) * ACT_LD + lane;      // lane + 64 cc < 256 <= ACT_LD: in the row
+        float sm = 0.f;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          const float d = (lane + 64 * cc < h) ? z[cc] - mean : 0.f;
-          sq += d * d;
+          const float t = zp[64 * cc];
+          z[rr][cc] = okc[cc] ? t : 0.f;
+          sm += z[rr][cc];
         }
-        rs = 1.0f / sqrtf(wave_sum(sq) / (float)h + a.eps);
-        if (lane == 0 && grow < a.B && L.rstd) L.rstd[grow] = rs;
+        mean[rr] = sm;
       }
-      const uint32_t rowkey = drop_rowkey(seed, L.layer_id, grow);
+      if (ln_on) {
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int col = lane + 64 * cc;
-        const float xh = a.layernorm ? (z[cc] - mean) * rs : z[cc];
-        const float u = fmaf(xh, gv[cc], bev[cc]);
-        float v = fmaxf(u, 0.f);
-        if (a.drop_p > 0.f) {
-          const bool keep = drop_keep(rowkey, col, drop_thr);
-          v = keep ? v * keep_scale : 0.f;
-        }
-        if (col < h) {
-          nxt[row * ACT_LD + col] = v;
-          if (grow < a.B && L.xhat) {          // NULL in eval mode: nothing is kept for a backward
-            L.xhat[(size_t)grow * h + col] = xh;
-            L.act[(size_t)grow * h + col] = v;
+        for (int rr = 0; rr < RPW; ++rr) mean[rr] = wave_sum(mean[rr]) / (float)h;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          float sq = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const float d = okc[cc] ? z[rr][cc] - mean[rr] : 0.f;
+            sq += d * d;
           }
+          rs[rr] = sq;
         }
-        if constexpr (BF) abf[row * ABF_LD + col] = col < h ? to_bf16(v) : (u16)0;     // next layer's A operand
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) rs[rr] = 1.0f / sqrtf(wave_sum(rs[rr]) / (float)h + a.eps);
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) { mean[rr] = 0.f; rs[rr] = 1.f; }
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = RPW * wave + rr;
+        const int grow = row0 + row;
+        float xh[4], v[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          xh[cc] = ln_on ? (z[rr][cc] - mean[rr]) * rs[rr] : z[rr][cc];
+          v[cc] = fmaxf(fmaf(xh[cc], gv[cc], bev[cc]), 0.f);
+        }
+        if (drop_on) {
+          const uint32_t rowkey = drop_rowkey(seed, lid, grow);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) v[cc] = drop_keep(rowkey, lane + 64 * cc, drop_thr) ? v[cc] * keep_scale : 0.f;
+        }
+        float *np = nxt + row * ACT_LD + lane;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          if (okc[cc]) np[64 * cc] = v[cc];
+        if constexpr (BF) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) abf[row * ABF_LD + lane + 64 * cc] = okc[cc] ? to_bf16(v[cc]) : (u16)0;     // next layer's A operand
+        }
+        if (xhat_p != nullptr && grow < a.B) {        // both wave-uniform
+          float *xp = xhat_p + (size_t)grow * h + lane, *ap = act_p + (size_t)grow * h + lane;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+            if (okc[cc]) { xp[64 * cc] = xh[cc]; ap[64 * cc] = v[cc]; }
+          if (ln_on && rstd_p != nullptr && lane == 0) rstd_p[grow] = rs[rr];
+        }
       }
     }
     STAMP(4 + 4 * (li < 0 ? 0 : li));
@@ -511,16 +578,120 @@ __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float *smem,
 // ---------------------------------------------------------------------------------------------
 // LDS floats of the backward body (the launch code sizes the dynamic segment with it)
 template <int MT, bool BF>
-constexpr size_t tail_bwd_lds_floats() {
+static constexpr size_t tail_bwd_lds_floats() {
   constexpr size_t R = 16 * MT;
   if (BF) return R * ACT_LD + (R * ABF_LD + 1) / 2 + 3 * NW * 256 + R * TAIL_MAXQ;
   return 2 * R * ACT_LD + (R * ACT_LD >= (size_t)3 * NW * 256 ? 0 : 3 * NW * 256) + R * TAIL_MAXQ;
 }
 
+// Head of the backward: dY of the tile's rows into LDS (sdy [R][Q]), dA_last = dY Wo into d0, and the partials of
+// dWo / dbo over the tile's rows into part_head[tile][Q*hl (dWo) | Q (dbo)].  `scr`: LDS scratch [TT/256][Q][256]
+// (32 / 64 rows), free until the first LayerNorm phase.  Q1: one output column.
+template <int MT, bool BF, bool Q1>
+static __device__ __forceinline__ void bwd_head(const TailBwdArgs &a, float *d0, float *scr, float *sdy, int row0, int tile,
+                                                int hl) {
+  constexpr int R = 16 * MT;
+  constexpr int QM = Q1 ? 1 : TAIL_MAXQ;
+  const int tid = threadIdx.x;
+  const int Q = Q1 ? 1 : a.Q;
+  if (Q1) {
+    if (tid < R) sdy[tid] = row0 + tid < a.B ? a.dY[row0 + tid] : 0.f;
+  } else if (tid < R * TAIL_MAXQ) {
+    const int row = tid / Q, qq = tid - row * Q;
+    sdy[tid] = (tid < R * Q && row0 + row < a.B) ? a.dY[(size_t)(row0 + row) * Q + qq] : 0.f;
+  }
+  // this thread's column of Wo (requested before the barrier), then its column of dA for every NG-th row
+  constexpr int NG = TT / 256;
+  const int g = tid >> 8, col = tid & 255;
+  const int colc = min(col, hl - 1);
+  float wo[QM];
+#pragma unroll
+  for (int qq = 0; qq < QM; ++qq) wo[qq] = a.Wo[min(qq, Q - 1) * hl + colc];
+  lds_barrier();
+  if (col < hl) {
+#pragma unroll
+    for (int i = 0; i < R / NG; ++i) {
+      const int r = g + NG * i;
+      float d = 0.f;
+#pragma unroll
+      for (int qq = 0; qq < QM; ++qq)
+        if (Q1 || qq < Q) d = fmaf(sdy[r * Q + qq], wo[qq], d);
+      d0[r * ACT_LD + col] = d;
+    }
+  }
+  float *ph = a.part_head + (size_t)tile * Q * (hl + 1);
+  const int nrow = min(R, a.B - row0);
+  if constexpr (MT == 1) {
+    if (tid < hl) {
+      float pw[QM];
+#pragma unroll
+      for (int qq = 0; qq < QM; ++qq) pw[qq] = 0.f;
+      // 16 rows of the last activations in flight at a time (clamped rows: sdy is 0 beyond the batch)
+      float av[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) av[r] = a.act_last[(size_t)min(row0 + r, a.B - 1) * hl + tid];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq)
+          if (Q1 || qq < Q) pw[qq] = fmaf(sdy[r * Q + qq], av[r], pw[qq]);
+#pragma unroll
+      for (int qq = 0; qq < QM; ++qq)
+        if (Q1 || qq < Q) ph[qq * hl + tid] = pw[qq];
+    }
+  } else {
+    // 32 / 64 rows: the column sums over the tile's rows by ALL waves -- groups of 256 threads take an equal share
+    // of the rows each (one batch of loads in flight per thread), their partials meet in LDS (the second gradient
+    // tile, or the column-partial scratch under bf16 operands: both unused until the first LayerNorm phase).  With
+    // the columns alone (128 threads of 1024 walking 64 rows in four dependent batches) this phase was 14 of the
+    // backward's 75 us per 64-row tile (round-2 stamps).
+    constexpr int RG = R / NG;
+    if (col < hl) {
+      float pw[QM];
+#pragma unroll
+      for (int qq = 0; qq < QM; ++qq) pw[qq] = 0.f;
+      float av[RG];
+#pragma unroll
+      for (int r = 0; r < RG; ++r) av[r] = a.act_last[(size_t)min(row0 + g * RG + r, a.B - 1) * hl + col];
+#pragma unroll
+      for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq)
+          if (Q1 || qq < Q) pw[qq] = fmaf(sdy[(g * RG + r) * Q + qq], av[r], pw[qq]);
+#pragma unroll
+      for (int qq = 0; qq < QM; ++qq)
+        if (Q1 || qq < Q) scr[(g * TAIL_MAXQ + qq) * 256 + col] = pw[qq];
+    }
+    lds_barrier();
+    if (Q1) {
+      if (tid < hl) {
+        float t = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < NG; ++gg) t += scr[gg * TAIL_MAXQ * 256 + tid];     // fixed order
+        ph[tid] = t;
+      }
+    } else {
+      for (int i = tid; i < Q * hl; i += TT) {
+        const int qq = i / hl, c2 = i - qq * hl;
+        float t = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < NG; ++gg) t += scr[(gg * TAIL_MAXQ + qq) * 256 + c2];     // fixed order
+        ph[qq * hl + c2] = t;
+      }
+    }
+  }
+  if (tid < Q) {
+    float sb = 0.f;
+    for (int row = 0; row < nrow; ++row) sb += sdy[row * Q + tid];
+    ph[Q * hl + tid] = sb;
+  }
+}
+
+
 // BF: dA = dZ W with bf16 operands (the transposed weight copies WTbf as the K-contiguous operand): ONE fp32
 // gradient tile (LayerNorm backward in place, the GEMM's output lands in it again) + the bf16 image of dZ.
 template <int MT, bool BF = false>
-__device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem, const int tile) {
+static __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem, const int tile) {
   constexpr int R = 16 * MT, RPW = (R + NW - 1) / NW;
   float *d0 = smem, *d1 = BF ? smem : smem + R * ACT_LD;
   u16 *abf = reinterpret_cast<u16 *>(smem + R * ACT_LD);
@@ -557,148 +728,105 @@ __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem,
   };
   ln_inputs(a.L[a.n_layers - 1]);
 
-  if (tid < R * TAIL_MAXQ) {
-    const int row = tid / a.Q, qq = tid - row * a.Q;
-    sdy[tid] = (tid < R * a.Q && row0 + row < a.B) ? a.dY[(size_t)(row0 + row) * a.Q + qq] : 0.f;
-  }
-  lds_barrier();
   const int hl = a.L[a.n_layers - 1].h;
-  for (int idx = tid; idx < R * hl; idx += TT) {
-    const int row = idx / hl, col = idx - row * hl;
-    float d = 0.f;
-    for (int qq = 0; qq < a.Q; ++qq) d = fmaf(sdy[row * a.Q + qq], a.Wo[qq * hl + col], d);
-    d0[row * ACT_LD + col] = d;
-  }
-  // output-layer weight gradient partials of this tile: part_head[blk][Q*hl (dWo) | Q (dbo)]
-  {
-    float *ph = a.part_head + (size_t)tile * a.Q * (hl + 1);
-    const int nrow = min(R, a.B - row0);
-    if constexpr (MT == 1) {
-      for (int col = tid; col < hl; col += TT) {
-        float pw[TAIL_MAXQ];
-#pragma unroll
-        for (int qq = 0; qq < TAIL_MAXQ; ++qq) pw[qq] = 0.f;
-        // 16 rows of the last activations in flight at a time (clamped rows: sdy is 0 beyond the batch)
-        float av[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          av[r] = a.act_last[(size_t)min(row0 + r, a.B - 1) * hl + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-          for (int qq = 0; qq < TAIL_MAXQ; ++qq)
-            if (qq < a.Q) pw[qq] = fmaf(sdy[r * a.Q + qq], av[r], pw[qq]);
-#pragma unroll
-        for (int qq = 0; qq < TAIL_MAXQ; ++qq)
-          if (qq < a.Q) ph[qq * hl + col] = pw[qq];
-      }
-    } else {
-      // 32 / 64 rows: the column sums over the tile's rows by ALL waves -- four groups of 256 threads take a
-      // quarter of the rows each (one batch of R/4 loads in flight per thread), their partials meet in LDS (the
-      // second gradient tile, or the column-partial scratch under bf16 operands: both unused until the first
-      // LayerNorm phase).  With the columns alone (128 threads of 1024 walking 64 rows in four dependent
-      // batches) this phase was 14 of the backward's 75 us per 64-row tile (round-2 stamps).
-      constexpr int NG = TT / 256, RG = R / NG;
-      float *scr = BF ? red_own : d1;                    // [NG][Q][256]
-      const int g = tid >> 8, col = tid & 255;
-      if (col < hl) {
-        float pw[TAIL_MAXQ];
-#pragma unroll
-        for (int qq = 0; qq < TAIL_MAXQ; ++qq) pw[qq] = 0.f;
-        float av[RG];
-#pragma unroll
-        for (int r = 0; r < RG; ++r)
-          av[r] = a.act_last[(size_t)min(row0 + g * RG + r, a.B - 1) * hl + col];
-#pragma unroll
-        for (int r = 0; r < RG; ++r)
-#pragma unroll
-          for (int qq = 0; qq < TAIL_MAXQ; ++qq)
-            if (qq < a.Q) pw[qq] = fmaf(sdy[(g * RG + r) * a.Q + qq], av[r], pw[qq]);
-#pragma unroll
-        for (int qq = 0; qq < TAIL_MAXQ; ++qq)
-          if (qq < a.Q) scr[(g * TAIL_MAXQ + qq) * 256 + col] = pw[qq];
-      }
-      lds_barrier();
-      for (int i = tid; i < a.Q * hl; i += TT) {
-        const int qq = i / hl, c2 = i - qq * hl;
-        float t = 0.f;
-#pragma unroll
-        for (int gg = 0; gg < NG; ++gg) t += scr[(gg * TAIL_MAXQ + qq) * 256 + c2];     // fixed order
-        ph[qq * hl + c2] = t;
-      }
-    }
-    if (tid < a.Q) {
-      float sb = 0.f;
-      for (int row = 0; row < nrow; ++row) sb += sdy[row * a.Q + tid];
-      ph[a.Q * hl + tid] = sb;
-    }
-  }
+  // head phase: dA of the last hidden layer and the output layer's weight-gradient partials of this tile; one
+  // output column (the MSE head) is its own instantiation -- with a run-time Q every fused multiply-add of the
+  // column sums sat behind a scalar branch
+  if (a.Q == 1) bwd_head<MT, BF, true>(a, d0, BF ? red_own : d1, sdy, row0, tile, hl);
+  else bwd_head<MT, BF, false>(a, d0, BF ? red_own : d1, sdy, row0, tile, hl);
   lds_barrier();
   const uint64_t seed = a.seed + (a.step_dev ? (uint64_t)a.step_dev[0] * 0x9E3779B97F4A7C15ULL : 0ULL);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const uint32_t drop_thr = drop_threshold(a.drop_p);
+  const bool drop_on = a.drop_p > 0.f, ln_on = a.layernorm != 0;      // scalar
   float *cur = d0, *nxt = d1;
   STAMP(1);                     // head phase done (dA of the last layer, dWo / dbo partials)
 
   for (int li = a.n_layers - 1; li >= 0; --li) {
     const TailLayer &L = a.L[li];
     const int h = L.h;
-    BFrag<1> wpre;
-    BFragH wpre_h;
+    BFrag<MAX_NI> wpre;
+    BFragH<MAX_NI> wpre_h;
     if (li > 0) {                                                       // for the dA GEMM at the end of this pass
       if constexpr (BF) preload_wh(wpre_h, L.WTbf, L.hp, h, wave, c16, q);
-      else preload_w_kn(wpre, L.W, L.hp, h, wave, c16, q);
+      else preload_w<true>(wpre, L.W, L.hp, h, wave, c16, q);
     }
     // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows RPW*w .. of this wave.  Its global inputs
     // (xhat rows, gamma, beta, rstd) were requested one phase early (ln_inputs below).
+    // Staged over the wave's rows like the forward phase: the masked gradient and the two row sums of every row,
+    // then the rows' reductions (independent chains), then dZ and its stores.
     float pg[4], pb[4], pz[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) pg[cc] = pb[cc] = pz[cc] = 0.f;
+    {
+      float *const dz_p = a.dZ[li];
+      const int lid = L.layer_id;
+      bool okc[4];
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int row = RPW * wave + rr;
-      const int grow = row0 + row;
-      const bool valid = grow < a.B;
-      float dxh[4];
-      float s1 = 0.f, s2 = 0.f;
-      const uint32_t rowkey = drop_rowkey(seed, L.layer_id, grow);
+      for (int cc = 0; cc < 4; ++cc) okc[cc] = lane + 64 * cc < h;
+      float dxh[RPW][4], m1[RPW], m2[RPW];
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int col = lane + 64 * cc;
-        const bool ok = valid && col < h;
-        const float x = xv[rr][cc];
-        const float u = fmaf(x, gv[cc], bev[cc]);
-        float d = cur[row * ACT_LD + min(col, TAIL_MAX_W - 1)];
-        if (a.drop_p > 0.f) {
-          const bool keep = drop_keep(rowkey, col, drop_thr);
-          d = keep ? d * keep_scale : 0.f;
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = RPW * wave + rr;
+        const int grow = row0 + row;
+        const bool valid = grow < a.B;                       // scalar
+        const float *cp = cur + row * ACT_LD + lane;        // lane + 64 cc < 256 <= ACT_LD: in the row
+        float d[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) d[cc] = cp[64 * cc];
+        if (drop_on) {
+          const uint32_t rowkey = drop_rowkey(seed, lid, grow);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) d[cc] = drop_keep(rowkey, lane + 64 * cc, drop_thr) ? d[cc] * keep_scale : 0.f;
         }
-        d = (ok && u > 0.f) ? d : 0.f;
-        if (a.layernorm) {
-          pg[cc] += d * x;
-          pb[cc] += d;
-          d *= gv[cc];
-          s1 += d;
-          s2 += d * x;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float x = xv[rr][cc];
+          const float u = fmaf(x, gv[cc], bev[cc]);
+          float dd = (valid && okc[cc] && u > 0.f) ? d[cc] : 0.f;
+          if (ln_on) {
+            pg[cc] += dd * x;
+            pb[cc] += dd;
+            dd *= gv[cc];
+            s1 += dd;
+            s2 += dd * x;
+          }
+          dxh[rr][cc] = dd;
         }
-        dxh[cc] = d;
+        m1[rr] = s1; m2[rr] = s2;
       }
-      float m1 = 0.f, m2 = 0.f;
-      if (a.layernorm) {
-        m1 = wave_sum(s1) / (float)h;
-        m2 = wave_sum(s2) / (float)h;
+      if (ln_on) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) m1[rr] = wave_sum(m1[rr]) / (float)h;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) m2[rr] = wave_sum(m2[rr]) / (float)h;
       }
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int col = lane + 64 * cc;
-        if (col < h) {
-          const float dz = (a.layernorm && valid) ? rsv[rr] * (dxh[cc] - m1 - xv[rr][cc] * m2) : dxh[cc];
-          cur[row * ACT_LD + col] = dz;
-          if (valid) a.dZ[li][(size_t)grow * h + col] = dz;
-          pz[cc] += dz;
-          if constexpr (BF) abf[row * ABF_LD + col] = to_bf16(dz);
-        } else if constexpr (BF) {
-          abf[row * ABF_LD + col] = (u16)0;          // columns h .. 255 of the image: zero (64-deep chunks)
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = RPW * wave + rr;
+        const int grow = row0 + row;
+        const bool valid = grow < a.B;
+        float dz[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          dz[cc] = (ln_on && valid) ? rsv[rr] * (dxh[rr][cc] - m1[rr] - xv[rr][cc] * m2[rr]) : dxh[rr][cc];
+          if (okc[cc]) pz[cc] += dz[cc];
+        }
+        float *cw = cur + row * ACT_LD + lane;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          if (okc[cc]) cw[64 * cc] = dz[cc];
+        if constexpr (BF) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)      // columns h .. 255 of the image: zero (64-deep chunks)
+            abf[row * ABF_LD + lane + 64 * cc] = okc[cc] ? to_bf16(dz[cc]) : (u16)0;
+        }
+        if (valid) {
+          float *gp = dz_p + (size_t)grow * h + lane;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+            if (okc[cc]) gp[64 * cc] = dz[cc];
         }
       }
     }
@@ -751,5 +879,7 @@ __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float *smem,
     float *tmp = cur; cur = nxt; nxt = tmp;
   }
 }
+
+};  // struct Tail<NW>
 
 }  // namespace stdadk
