@@ -126,6 +126,11 @@ __device__ __forceinline__ void read_frag(const float *lds, int row, int s, int 
   }
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains every global access in flight
+__device__ __forceinline__ void gemm_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int BM, int BN, bool A_KM, bool B_KM, int VA, int VB>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by, int bz, float *lds) {
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -208,6 +213,91 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by
 }
 
 // ---------------------------------------------------------------------------------------------
+// The tile of the grouped weight-gradient products: C[64 x 64] (slab of split bz) = A^T B over a K slice, fp32, both
+// operands K-major ([k][rows], 16-byte aligned, row stride a multiple of 4: gemm_tn_groupable).
+// The generic body above masks a loaded value in registers right behind its load (rows / k beyond the operand), which
+// makes the wave wait for the load BEFORE the MFMAs of the current step: loads and matrix work take turns (ablation,
+// round 2: 8.5 us of MFMA + 3 us of loads + 3 us of slab stores + 7 us of skeleton = the kernel's 21.7 us at 4 096 rows,
+// 128 + 100 us of 247 at 65 536).  Here a step's loads are RAW -- unconditional, from clamped addresses, untouched until
+// they are written to LDS one step later, where the masks are applied -- and the barriers order LDS traffic only
+// (__syncthreads() would drain the loads in flight), so the next step's operands travel while this step multiplies.
+// ---------------------------------------------------------------------------------------------
+// thread t: k-rows t/16 and t/16 + 16 of the stage, rows 4 (t % 16) .. + 3 of the tile
+__device__ __forceinline__ void tn_load_raw(const float *__restrict__ P, int64_t ld, int r0, int nrows, int k0, int kend,
+                                            float4 *reg) {
+  const int tid = threadIdx.x;
+  const int r = r0 + (tid & 15) * 4;
+  const int rc = r < nrows ? r : r0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = k0 + (tid >> 4) + 16 * i;
+    reg[i] = *reinterpret_cast<const float4 *>(P + (int64_t)(k < kend ? k : k0) * ld + rc);
+  }
+}
+__device__ __forceinline__ void tn_store_masked(float *lds, const float4 *reg, int r0, int nrows, int k0, int kend) {
+  const int tid = threadIdx.x;
+  const int r = r0 + (tid & 15) * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int kk = (tid >> 4) + 16 * i;
+    const bool kok = k0 + kk < kend;
+    *reinterpret_cast<float4 *>(lds + kk * 64 + (tid & 15) * 4) =
+        make_float4((kok && r + 0 < nrows) ? reg[i].x : 0.f, (kok && r + 1 < nrows) ? reg[i].y : 0.f,
+                    (kok && r + 2 < nrows) ? reg[i].z : 0.f, (kok && r + 3 < nrows) ? reg[i].w : 0.f);
+  }
+}
+
+__device__ __forceinline__ void gemm_tn_tile_body_f32(const GemmArgs &g, int bx, int by, int bz, float *lds) {
+  static_assert(TileGeom<64, true>::SIZE == BK * 64 && GT == 256 && BK == 32, "tn_load_raw / tn_store_masked geometry");
+  float *As = lds, *Bs = lds + BK * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = by * 64, n0 = bx * 64;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  int kbeg = 0, kend = g.K;
+  if (g.splits > 1) {
+    kbeg = bz * g.kps;
+    kend = min(g.K, kbeg + g.kps);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 ra[2], rb[2];
+  if (kbeg < kend) {
+    tn_load_raw(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+    tn_load_raw(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    tn_store_masked(As, ra, m0, g.M, k0, kend);
+    tn_store_masked(Bs, rb, n0, g.N, k0, kend);
+    gemm_lds_barrier();
+    if (k0 + BK < kend) {      // scalar
+      tn_load_raw(g.A, g.lda, m0, g.M, k0 + BK, kend, ra);
+      tn_load_raw(g.B, g.ldb, n0, g.N, k0 + BK, kend, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      float fa[4], fb[4];
+      read_frag<64, true>(As, wm, s, lane, fa);
+      read_frag<64, true>(Bs, wn, s, lane, fb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+    }
+    gemm_lds_barrier();
+  }
+  // epilogue: always a slab (grouped jobs); acc reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its tile
+  float *Cbase = g.slab + (int64_t)bz * g.slab_stride;
+  const int h = lane >> 5, cl = lane & 31;
+  const int col = n0 + wn + cl;
+  if (col < g.N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < g.M) Cbase[(int64_t)row * g.N + col] = acc[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bf16 operands for the TN products of a step (STDADK_FLAG_BF16): C[64 x 64] = A^T B over a K slice, both operands
 // stored K-major in fp32 ([k][rows]).  The tiles are rounded to bf16 as they are stored to LDS (the operand
 // boundary), [64 k][64 rows] images with a 96-element row stride, and the K-contiguous fragments the MFMA wants
@@ -230,27 +320,31 @@ __device__ __forceinline__ uint32_t h_pack(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
-// rows r0.. of k-rows k0.. of a K-major fp32 operand into registers: 4 float4 per thread, unconditional clamped
-// loads masked in registers (see load_tile)
+// rows r0.. of k-rows k0.. of a K-major fp32 operand into registers: 4 float4 per thread, unconditional RAW loads from
+// clamped addresses; the masks (rows / k beyond the operand) are applied when the values are rounded and written to
+// LDS one stage later (see gemm_tn_tile_body_f32: a value touched right behind its load makes the wave wait for it
+// before the MFMAs of the current stage)
 __device__ __forceinline__ void h_load(const float *__restrict__ P, int64_t ld, int r0, int nrows, int k0, int kend,
                                        float4 *reg) {
+  const int tid = threadIdx.x;
+  const int r = r0 + (tid & 15) * 4;
+  const int rc = r < nrows ? r : r0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + (tid >> 4) + 16 * i;
+    reg[i] = *reinterpret_cast<const float4 *>(P + (int64_t)(k < kend ? k : k0) * ld + rc);
+  }
+}
+__device__ __forceinline__ void h_store(hu16 *lds, const float4 *reg, int r0, int nrows, int k0, int kend) {
   const int tid = threadIdx.x;
   const int r = r0 + (tid & 15) * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int kk = (tid >> 4) + 16 * i;
-    const bool kok = (k0 + kk) < kend;
-    const float4 v = *reinterpret_cast<const float4 *>(P + (int64_t)(kok ? k0 + kk : k0) * ld + (r < nrows ? r : r0));
-    reg[i] = make_float4((kok && r + 0 < nrows) ? v.x : 0.f, (kok && r + 1 < nrows) ? v.y : 0.f,
-                         (kok && r + 2 < nrows) ? v.z : 0.f, (kok && r + 3 < nrows) ? v.w : 0.f);
-  }
-}
-__device__ __forceinline__ void h_store(hu16 *lds, const float4 *reg) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int kk = (tid >> 4) + 16 * i;
-    *reinterpret_cast<uint2 *>(lds + kk * HSTRIDE + (tid & 15) * 4) = make_uint2(h_pack(reg[i].x, reg[i].y), h_pack(reg[i].z, reg[i].w));
+    const bool kok = k0 + kk < kend;
+    const float x = (kok && r + 0 < nrows) ? reg[i].x : 0.f, y = (kok && r + 1 < nrows) ? reg[i].y : 0.f;
+    const float z = (kok && r + 2 < nrows) ? reg[i].z : 0.f, w = (kok && r + 3 < nrows) ? reg[i].w : 0.f;
+    *reinterpret_cast<uint2 *>(lds + kk * HSTRIDE + (tid & 15) * 4) = make_uint2(h_pack(x, y), h_pack(z, w));
   }
 }
 // fragment of the 16-deep k-step s for the 32 rows starting at `row`: two transposing reads (k = 8h + 0..3, + 4..7)
@@ -284,9 +378,9 @@ __device__ __forceinline__ void gemm_tn_tile_body_h(const GemmArgs &g, int bx, i
     h_load(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
   }
   for (int k0 = kbeg; k0 < kend; k0 += BKH) {
-    h_store(As, ra);
-    h_store(Bs, rb);
-    __syncthreads();
+    h_store(As, ra, m0, g.M, k0, kend);
+    h_store(Bs, rb, n0, g.N, k0, kend);
+    gemm_lds_barrier();
     if (k0 + BKH < kend) {
       h_load(g.A, g.lda, m0, g.M, k0 + BKH, kend, ra);
       h_load(g.B, g.ldb, n0, g.N, k0 + BKH, kend, rb);
@@ -294,7 +388,7 @@ __device__ __forceinline__ void gemm_tn_tile_body_h(const GemmArgs &g, int bx, i
 #pragma unroll
     for (int s = 0; s < BKH / 16; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h_frag(As, wm, s, lane), h_frag(Bs, wn, s, lane), acc, 0, 0, 0);
-    __syncthreads();
+    gemm_lds_barrier();
   }
   // epilogue as the fp32 tiles: always a slab (grouped jobs)
   float *Cbase = g.slab + (int64_t)bz * g.slab_stride;
@@ -316,10 +410,24 @@ __device__ __forceinline__ void gemm_tn_grouped_block(const GemmGroup &grp, int 
   const GemmArgs &g = grp.job[j];
   int b = block - grp.first_block[j];
   const int tn = (g.N + 63) >> 6, tm = (g.M + 63) >> 6;
-  const int bz = b / (tn * tm);
-  b -= bz * tn * tm;
+  if (b >= tn * tm * g.splits) return;        // padding in front of the next job's aligned first block
+  int bz;
+  if (g.xcd_split) {
+    // XCD-aware order (a job's first block is a multiple of 8 and workgroups go to the XCDs round-robin, so b & 7 is
+    // the XCD): XCD x takes the x-th contiguous eighth of the K slices of EVERY output tile, i.e. one eighth of the
+    // rows of both operands -- each XCD's L2 then fetches an eighth of dZ / activations instead of all of them (the
+    // operands were written by the previous launch on other XCDs: every first touch is a fabric read).  The sorted
+    // batch is cell-ordered, so that eighth is also the stripe of the domain whose dZ_0 rows the knot groups of the
+    // same XCD gather (l1_window_bwd_multi_body).
+    const int x = b & 7, i = b >> 3, spx = g.splits >> 3;      // splits is a multiple of 8
+    bz = x * spx + i % spx;
+    b = i / spx;
+  } else {
+    bz = b / (tn * tm);
+    b -= bz * tn * tm;
+  }
   if (g.bf16) gemm_tn_tile_body_h(g, b % tn, b / tn, bz, lds);      // workgroup-uniform
-  else gemm_tile_body<64, 64, true, true, 4, 4>(g, b % tn, b / tn, bz, lds);
+  else gemm_tn_tile_body_f32(g, b % tn, b / tn, bz, lds);
 }
 
 }  // namespace stdadk

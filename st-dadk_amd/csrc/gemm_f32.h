@@ -27,6 +27,7 @@ struct GemmArgs {
   int always_slab = 0;  // write the (single) partial to the slab even when splits == 1
   int bf16 = 0;         // grouped TN jobs only (STDADK_FLAG_BF16): operands rounded to bf16 as they enter LDS,
                         // v_mfma_f32_32x32x16_bf16, fp32 accumulate
+  int xcd_split = 0;    // grouped TN jobs only, set by gemm_tn_grouped_prepare: XCD-aware block order (splits % 8 == 0)
 };
 
 // a table of TN products for one launch (gemm_tn_grouped_kernel) and of partial-sum reductions

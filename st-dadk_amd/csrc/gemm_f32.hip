@@ -124,6 +124,12 @@ int gemm_tn_grouped_prepare(GemmGroup &grp, int *n_blocks) {
     GemmArgs &g = grp.job[j];
     STDADK_REQUIRE(g.slab && g.kps % BK == 0 && g.splits >= 1, STDADK_E_ARG, "grouped gemm: bad job %d", j);
     g.always_slab = 1;
+    // XCD-aware order of a job's blocks (gemm_tn_grouped_block) when its K slices deal evenly to the 8 XCDs; its
+    // first block is then a multiple of 8 (the blocks before it are padding that returns at once).
+    // Environment STDADK_GEMM_XCD=0: plain order (diagnostic).
+    static const bool xcd_off = [] { const char *e = getenv("STDADK_GEMM_XCD"); return e && e[0] == '0'; }();
+    g.xcd_split = (!xcd_off && g.splits >= 8 && g.splits % 8 == 0) ? 1 : 0;
+    if (g.xcd_split) nb = (nb + 7) & ~7;
     grp.first_block[j] = nb;
     nb += (int)(ceil_div(g.M, 64) * ceil_div(g.N, 64)) * g.splits;
   }
