@@ -19,12 +19,14 @@ struct TileGeom {
 
 // Global -> registers for one operand tile.  `r0` first row (m or n) of the tile, `k0` first k.
 // VEC = contiguous floats per load along the operand's contiguous dimension.
+// Every load is UNCONDITIONAL from a clamped, always-valid address (the tile's first row / k when out of range) and
+// stays RAW in its registers: the masks for rows / k beyond the operand are applied by store_tile, when the values go
+// to LDS one K step later.  A conditional load gets its own branch and a vmcnt(0); a value masked right behind its
+// load makes the wave wait for the load BEFORE the MFMAs of the current step -- either way loads and matrix work
+// would take turns instead of overlapping (round-2 ablation, profiles/r02_grouped_gemm_ablation.txt).
 template <int ROWS, bool KM, int VEC>
 __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t ld, int r0, int nrows,
                                           int k0, int kend, float *reg) {
-  // Every load is UNCONDITIONAL from a clamped, always-valid address (the tile's first row / k when
-  // out of range) and masked in registers afterwards: a conditional load gets its own branch and a
-  // vmcnt(0), which would serialise the register-prefetch pipeline of the K loop.
   const int tid = threadIdx.x;
   constexpr int N_VEC = TileGeom<ROWS, KM>::ELEMS / VEC;
   if (!KM) {
@@ -35,21 +37,15 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t l
       const int row = tid / VPR + i * RPP;
       const int k = k0 + (tid % VPR) * VEC;
       const bool rok = (r0 + row) < nrows;
-      const bool ok = rok && k < kend;
       const float *src = P + (int64_t)(rok ? r0 + row : r0) * ld + (k < kend ? k : k0);
       if (VEC == 4) {
         const float4 v = *reinterpret_cast<const float4 *>(src);
-        reg[i * 4 + 0] = (ok && k + 0 < kend) ? v.x : 0.f;
-        reg[i * 4 + 1] = (ok && k + 1 < kend) ? v.y : 0.f;
-        reg[i * 4 + 2] = (ok && k + 2 < kend) ? v.z : 0.f;
-        reg[i * 4 + 3] = (ok && k + 3 < kend) ? v.w : 0.f;
+        reg[i * 4 + 0] = v.x; reg[i * 4 + 1] = v.y; reg[i * 4 + 2] = v.z; reg[i * 4 + 3] = v.w;
       } else if (VEC == 2) {
         const float2 v = *reinterpret_cast<const float2 *>(src);
-        reg[i * 2 + 0] = (ok && k + 0 < kend) ? v.x : 0.f;
-        reg[i * 2 + 1] = (ok && k + 1 < kend) ? v.y : 0.f;
+        reg[i * 2 + 0] = v.x; reg[i * 2 + 1] = v.y;
       } else {
-        const float v = *src;
-        reg[i] = ok ? v : 0.f;
+        reg[i] = *src;
       }
     }
   } else {
@@ -60,54 +56,57 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t l
       const int kk = tid / VPR + i * KPP;
       const int r = r0 + (tid % VPR) * VEC;
       const bool kok = (k0 + kk) < kend;
-      const bool ok = kok && r < nrows;
       const float *src = P + (int64_t)(kok ? k0 + kk : k0) * ld + (r < nrows ? r : r0);
       if (VEC == 4) {
         const float4 v = *reinterpret_cast<const float4 *>(src);
-        reg[i * 4 + 0] = (ok && r + 0 < nrows) ? v.x : 0.f;
-        reg[i * 4 + 1] = (ok && r + 1 < nrows) ? v.y : 0.f;
-        reg[i * 4 + 2] = (ok && r + 2 < nrows) ? v.z : 0.f;
-        reg[i * 4 + 3] = (ok && r + 3 < nrows) ? v.w : 0.f;
+        reg[i * 4 + 0] = v.x; reg[i * 4 + 1] = v.y; reg[i * 4 + 2] = v.z; reg[i * 4 + 3] = v.w;
       } else if (VEC == 2) {
         const float2 v = *reinterpret_cast<const float2 *>(src);
-        reg[i * 2 + 0] = (ok && r + 0 < nrows) ? v.x : 0.f;
-        reg[i * 2 + 1] = (ok && r + 1 < nrows) ? v.y : 0.f;
+        reg[i * 2 + 0] = v.x; reg[i * 2 + 1] = v.y;
       } else {
-        const float v = *src;
-        reg[i] = ok ? v : 0.f;
+        reg[i] = *src;
       }
     }
   }
 }
 
+// Registers -> LDS image, with the masks of the tile (the same (r0, nrows, k0, kend) the values were loaded with):
+// element (row, k) is kept when row < nrows and k < kend, else 0.
 template <int ROWS, bool KM, int VEC>
-__device__ __forceinline__ void store_tile(float *lds, const float *reg) {
+__device__ __forceinline__ void store_tile(float *lds, const float *reg, int r0, int nrows, int k0, int kend) {
   const int tid = threadIdx.x;
   constexpr int N_VEC = TileGeom<ROWS, KM>::ELEMS / VEC;
   constexpr int STRIDE = TileGeom<ROWS, KM>::STRIDE;
+  float m[VEC];
   if (!KM) {
     constexpr int VPR = BK / VEC;
     constexpr int RPP = GT / VPR;
 #pragma unroll
     for (int i = 0; i < N_VEC; ++i) {
-      int row = tid / VPR + i * RPP;
-      int k = (tid % VPR) * VEC;
-      float *dst = lds + row * STRIDE + k;
-      if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(reg[i * 4], reg[i * 4 + 1], reg[i * 4 + 2], reg[i * 4 + 3]);
-      else if (VEC == 2) *reinterpret_cast<float2 *>(dst) = make_float2(reg[i * 2], reg[i * 2 + 1]);
-      else *dst = reg[i];
+      const int row = tid / VPR + i * RPP;
+      const int kl = (tid % VPR) * VEC;
+      const bool rok = (r0 + row) < nrows;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) m[e] = (rok && k0 + kl + e < kend) ? reg[i * VEC + e] : 0.f;
+      float *dst = lds + row * STRIDE + kl;
+      if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(m[0], m[1], m[2], m[3]);
+      else if (VEC == 2) *reinterpret_cast<float2 *>(dst) = make_float2(m[0], m[1]);
+      else *dst = m[0];
     }
   } else {
     constexpr int VPR = ROWS / VEC;
     constexpr int KPP = GT / VPR;
 #pragma unroll
     for (int i = 0; i < N_VEC; ++i) {
-      int kk = tid / VPR + i * KPP;
-      int r = (tid % VPR) * VEC;
-      float *dst = lds + kk * STRIDE + r;
-      if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(reg[i * 4], reg[i * 4 + 1], reg[i * 4 + 2], reg[i * 4 + 3]);
-      else if (VEC == 2) *reinterpret_cast<float2 *>(dst) = make_float2(reg[i * 2], reg[i * 2 + 1]);
-      else *dst = reg[i];
+      const int kk = tid / VPR + i * KPP;
+      const int rl = (tid % VPR) * VEC;
+      const bool kok = (k0 + kk) < kend;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) m[e] = (kok && r0 + rl + e < nrows) ? reg[i * VEC + e] : 0.f;
+      float *dst = lds + kk * STRIDE + rl;
+      if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(m[0], m[1], m[2], m[3]);
+      else if (VEC == 2) *reinterpret_cast<float2 *>(dst) = make_float2(m[0], m[1]);
+      else *dst = m[0];
     }
   }
 }
@@ -161,9 +160,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by
     load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
   }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    store_tile<BM, A_KM, VA>(As, ra);
-    store_tile<BN, B_KM, VB>(Bs, rb);
-    __syncthreads();
+    store_tile<BM, A_KM, VA>(As, ra, m0, g.M, k0, kend);
+    store_tile<BN, B_KM, VB>(Bs, rb, n0, g.N, k0, kend);
+    gemm_lds_barrier();
     if (k0 + BK < kend) {
       load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, k0 + BK, kend, ra);
       load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, k0 + BK, kend, rb);
@@ -183,7 +182,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+    gemm_lds_barrier();
   }
 
   // epilogue: acc reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile
@@ -213,91 +212,6 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by
 }
 
 // ---------------------------------------------------------------------------------------------
-// The tile of the grouped weight-gradient products: C[64 x 64] (slab of split bz) = A^T B over a K slice, fp32, both
-// operands K-major ([k][rows], 16-byte aligned, row stride a multiple of 4: gemm_tn_groupable).
-// The generic body above masks a loaded value in registers right behind its load (rows / k beyond the operand), which
-// makes the wave wait for the load BEFORE the MFMAs of the current step: loads and matrix work take turns (ablation,
-// round 2: 8.5 us of MFMA + 3 us of loads + 3 us of slab stores + 7 us of skeleton = the kernel's 21.7 us at 4 096 rows,
-// 128 + 100 us of 247 at 65 536).  Here a step's loads are RAW -- unconditional, from clamped addresses, untouched until
-// they are written to LDS one step later, where the masks are applied -- and the barriers order LDS traffic only
-// (__syncthreads() would drain the loads in flight), so the next step's operands travel while this step multiplies.
-// ---------------------------------------------------------------------------------------------
-// thread t: k-rows t/16 and t/16 + 16 of the stage, rows 4 (t % 16) .. + 3 of the tile
-__device__ __forceinline__ void tn_load_raw(const float *__restrict__ P, int64_t ld, int r0, int nrows, int k0, int kend,
-                                            float4 *reg) {
-  const int tid = threadIdx.x;
-  const int r = r0 + (tid & 15) * 4;
-  const int rc = r < nrows ? r : r0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int k = k0 + (tid >> 4) + 16 * i;
-    reg[i] = *reinterpret_cast<const float4 *>(P + (int64_t)(k < kend ? k : k0) * ld + rc);
-  }
-}
-__device__ __forceinline__ void tn_store_masked(float *lds, const float4 *reg, int r0, int nrows, int k0, int kend) {
-  const int tid = threadIdx.x;
-  const int r = r0 + (tid & 15) * 4;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int kk = (tid >> 4) + 16 * i;
-    const bool kok = k0 + kk < kend;
-    *reinterpret_cast<float4 *>(lds + kk * 64 + (tid & 15) * 4) =
-        make_float4((kok && r + 0 < nrows) ? reg[i].x : 0.f, (kok && r + 1 < nrows) ? reg[i].y : 0.f,
-                    (kok && r + 2 < nrows) ? reg[i].z : 0.f, (kok && r + 3 < nrows) ? reg[i].w : 0.f);
-  }
-}
-
-__device__ __forceinline__ void gemm_tn_tile_body_f32(const GemmArgs &g, int bx, int by, int bz, float *lds) {
-  static_assert(TileGeom<64, true>::SIZE == BK * 64 && GT == 256 && BK == 32, "tn_load_raw / tn_store_masked geometry");
-  float *As = lds, *Bs = lds + BK * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = by * 64, n0 = bx * 64;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  int kbeg = 0, kend = g.K;
-  if (g.splits > 1) {
-    kbeg = bz * g.kps;
-    kend = min(g.K, kbeg + g.kps);
-  }
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float4 ra[2], rb[2];
-  if (kbeg < kend) {
-    tn_load_raw(g.A, g.lda, m0, g.M, kbeg, kend, ra);
-    tn_load_raw(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    tn_store_masked(As, ra, m0, g.M, k0, kend);
-    tn_store_masked(Bs, rb, n0, g.N, k0, kend);
-    gemm_lds_barrier();
-    if (k0 + BK < kend) {      // scalar
-      tn_load_raw(g.A, g.lda, m0, g.M, k0 + BK, kend, ra);
-      tn_load_raw(g.B, g.ldb, n0, g.N, k0 + BK, kend, rb);
-    }
-#pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      float fa[4], fb[4];
-      read_frag<64, true>(As, wm, s, lane, fa);
-      read_frag<64, true>(Bs, wn, s, lane, fb);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
-    }
-    gemm_lds_barrier();
-  }
-  // epilogue: always a slab (grouped jobs); acc reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its tile
-  float *Cbase = g.slab + (int64_t)bz * g.slab_stride;
-  const int h = lane >> 5, cl = lane & 31;
-  const int col = n0 + wn + cl;
-  if (col < g.N) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < g.M) Cbase[(int64_t)row * g.N + col] = acc[r];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // bf16 operands for the TN products of a step (STDADK_FLAG_BF16): C[64 x 64] = A^T B over a K slice, both operands
 // stored K-major in fp32 ([k][rows]).  The tiles are rounded to bf16 as they are stored to LDS (the operand
 // boundary), [64 k][64 rows] images with a 96-element row stride, and the K-contiguous fragments the MFMA wants
@@ -322,8 +236,8 @@ __device__ __forceinline__ uint32_t h_pack(float a, float b) {
 
 // rows r0.. of k-rows k0.. of a K-major fp32 operand into registers: 4 float4 per thread, unconditional RAW loads from
 // clamped addresses; the masks (rows / k beyond the operand) are applied when the values are rounded and written to
-// LDS one stage later (see gemm_tn_tile_body_f32: a value touched right behind its load makes the wave wait for it
-// before the MFMAs of the current stage)
+// LDS one stage later (see load_tile: a value touched right behind its load makes the wave wait for it before the
+// MFMAs of the current stage)
 __device__ __forceinline__ void h_load(const float *__restrict__ P, int64_t ld, int r0, int nrows, int k0, int kend,
                                        float4 *reg) {
   const int tid = threadIdx.x;
@@ -427,7 +341,7 @@ __device__ __forceinline__ void gemm_tn_grouped_block(const GemmGroup &grp, int 
     b -= bz * tn * tm;
   }
   if (g.bf16) gemm_tn_tile_body_h(g, b % tn, b / tn, bz, lds);      // workgroup-uniform
-  else gemm_tn_tile_body_f32(g, b % tn, b / tn, bz, lds);
+  else gemm_tile_body<64, 64, true, true, 4, 4>(g, b % tn, b / tn, bz, lds);
 }
 
 }  // namespace stdadk
