@@ -271,7 +271,27 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
     if (a.psi)
       for (int j = Kt + lane; j < a.ld_psi; j += 64) a.psi[(size_t)row * a.ld_psi + j] = 0.f;
     __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < Kt; ++j) fma_row<CPL>(acc, my_psi[j], Wt + (size_t)j * H + CPL * lane);
+    {
+      // eight rows of the LDS image in flight (a row at a time is a chain of Kt dependent LDS round trips); same
+      // order of the multiply-adds
+      int j = 0;
+      for (; j + 8 <= Kt; j += 8) {
+        float pv[8];
+        typename VecT<CPL>::T wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pv[e] = my_psi[j + e];
+          wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(Wt + (size_t)(j + e) * H + CPL * lane);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float *f = reinterpret_cast<const float *>(&wv[e]);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[c] = fmaf(pv[e], f[c], acc[c]);
+        }
+      }
+      for (; j < Kt; ++j) fma_row<CPL>(acc, my_psi[j], Wt + (size_t)j * H + CPL * lane);
+    }
     __builtin_amdgcn_wave_barrier();
 
     // ---- LayerNorm -> ReLU -> Dropout (row-local: this wave owns the whole row)
@@ -510,14 +530,36 @@ __device__ __forceinline__ void l1_window_fwd_multi_body(const L1FwdArgs &a, flo
         for (int j = Kt + lane; j < a.ld_psi; j += 64) a.psi[(size_t)(row + r) * a.ld_psi + j] = 0.f;
     }
     __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < Kt; ++j) {
-      typename VecT<CPL>::T v = *reinterpret_cast<const typename VecT<CPL>::T *>(Wt + (size_t)j * H + CPL * lane);
-      const float *f = reinterpret_cast<const float *>(&v);
+    {
+      // four rows of the LDS image (and their R factors) in flight; same order of the multiply-adds
+      int j = 0;
+      for (; j + 4 <= Kt; j += 4) {
+        typename VecT<CPL>::T wv[4];
+        float sv[4][R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float s = my_psi[j * R + r];
+        for (int e = 0; e < 4; ++e) {
+          wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(Wt + (size_t)(j + e) * H + CPL * lane);
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) acc[r][c] = fmaf(s, f[c], acc[r][c]);
+          for (int r = 0; r < R; ++r) sv[e][r] = my_psi[(j + e) * R + r];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float *f = reinterpret_cast<const float *>(&wv[e]);
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[r][c] = fmaf(sv[e][r], f[c], acc[r][c]);
+        }
+      }
+      for (; j < Kt; ++j) {
+        typename VecT<CPL>::T v = *reinterpret_cast<const typename VecT<CPL>::T *>(Wt + (size_t)j * H + CPL * lane);
+        const float *f = reinterpret_cast<const float *>(&v);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float s = my_psi[j * R + r];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[r][c] = fmaf(s, f[c], acc[r][c]);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
