@@ -20,24 +20,35 @@ void set_error(const char *fmt, ...) {
 }
 
 // ---- per-launch HIP-event profiler (off by default; not thread-safe, one stream at a time)
+// Events without the system-scope fence (both records are on the launch stream of one device): a default event's
+// record makes the command processor write back / invalidate the caches around the kernel it brackets, which the
+// bracket then counts as kernel time.  The events are pooled: nothing is created on the launch path.
 bool g_prof_on = false;
 struct ProfRec { std::string name; hipEvent_t e0, e1; };
 static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+static bool prof_event(hipEvent_t *e) {
+  if (!g_pool.empty()) { *e = g_pool.back(); g_pool.pop_back(); return true; }
+  if (hipEventCreateWithFlags(e, hipEventDisableSystemFence) == hipSuccess) return true;
+  (void)hipGetLastError();
+  return hipEventCreate(e) == hipSuccess;
+}
 
 void prof_before(const char *name, hipStream_t st) {
   ProfRec r;
   r.name = name;
-  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-  hipEventRecord(r.e0, st);
+  if (!prof_event(&r.e0) || !prof_event(&r.e1)) return;
+  (void)hipEventRecord(r.e0, st);
   g_recs.push_back(r);
 }
 void prof_after(hipStream_t st) {
-  if (!g_recs.empty()) hipEventRecord(g_recs.back().e1, st);
+  if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, st);
 }
 }  // namespace stdadk
 
 extern "C" int stdadk_profile_enable(int32_t on) {
-  for (auto &r : stdadk::g_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (auto &r : stdadk::g_recs) { stdadk::g_pool.push_back(r.e0); stdadk::g_pool.push_back(r.e1); }
   stdadk::g_recs.clear();
   stdadk::g_prof_on = on != 0;
   return 0;
