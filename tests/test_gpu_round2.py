@@ -644,3 +644,48 @@ def test_scattered_knots_engine_and_grid_inference():
     yg = pr.predict_grid(sites, tv)
     yr = pr.predict(sites.repeat(Tn, 1), tv.repeat_interleave(S)).view(Tn, S, 1)
     assert (yg - yr).abs().max().item() <= 2e-6 * max(1.0, yr.abs().max().item())
+
+
+# ------------------------------------------------------------------ Q > 1 heads on the 32- and 64-row tiles
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [9000, 20000])
+def test_quantile_step_on_large_row_tiles(B):
+    """The fused step with a 5-quantile head (check loss + non-crossing penalty inside the launch) at batch sizes
+    whose tail launches carry 32 (B = 9000) and 64 (B = 20000) rows per workgroup: the head of the backward sums
+    the output layer's weight-gradient partials over row groups that meet in LDS there (one group per 16-row tile
+    below 8192 rows, which the golden cases cover).  lr = 0, so the engine's gradient buffer is the gradient of
+    the reference's objective at the golden weights: against the float64 oracle."""
+    from golden import cases
+    from oracle import stdadk_oracle as orc
+    from stnf.engine import TrainStep
+    from stnf.models import STInterpMLP
+    cfg, lc = cases.quantile_cfg("default227_mq5")
+    cfg = dict(cfg, B=B, seed=500 + B % 97)
+    X, coords, t, y = cases.make_inputs(cfg)
+    st = cases.make_state(cfg)
+    d = torch.device("cuda", 0)
+    m = STInterpMLP(p=cfg["p"], k_spatial_centers=cfg["k_spatial_centers"], k_temporal_centers=cfg["k_temporal_centers"],
+                    hidden_dims=cfg["hidden_dims"], dropout=0.0, layernorm=cfg["layernorm"],
+                    spatial_basis_function=cfg["basis"], output_dim=cfg["output_dim"])
+    with torch.no_grad():
+        for (_, p), (k, v) in zip(m.named_parameters(), st.items()):
+            p.copy_(torch.from_numpy(v.copy()))
+    m.force_window_path = True
+    m = m.to(d).train()
+    eng = TrainStep(m, lr=0.0, weight_decay=0.0, grad_clip=0.0, ema_decay=0.99, max_batch=B, loss="pinball",
+                    quantile_levels=lc["taus"], non_crossing_weight=lc["nc_weight"], non_crossing_power=lc["nc_power"])
+    assert eng.uses_window
+    eng.step(None, *(torch.from_numpy(a).to(d) for a in (coords, t, y)))
+    loss = eng.mean_loss()
+    yo, lo, go = orc.quantile_step_grads(X, coords, t, y, st, cfg, lc)
+    assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (loss, lo)
+    first_w = m._body[0].weight
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert len(names) == len(eng.grad_views)
+    for n, gv in zip(names, eng.grad_views):
+        got = gv.detach().cpu().numpy()
+        ref = go[n]
+        if dict(m.named_parameters())[n] is first_w:
+            ref = ref.T                                   # the engine keeps W0 (and dW0) transposed
+        err = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert err <= 2e-5, (n, err)
