@@ -145,3 +145,48 @@ def test_host_model_runs_the_reference_style_batch_body():
     assert any(not torch.equal(a, p) for a, p in zip(before, m.parameters()))
     ema.restore()
     assert all(torch.equal(a, p) for a, p in zip(before, m.parameters()))
+
+
+# ------------------------------------------------------------------ dense-grid predictions + predictions.npz
+def test_predict_all_times_host_and_npz_record(tmp_path):
+    """The driver's dense-grid loop (scripts/train_st_interp.py:1228-1248) and its predictions.npz
+    (:2551-2560): time slices t_idx / (T - 1), the median column of a multi-quantile model, float64 (T, S);
+    the record carries the reference's six keys with the arrays unchanged."""
+    from stnf.models import STInterpMLP
+    from stnf.utils.predictions import NPZ_KEYS, predict_all_times, save_predictions_npz
+    torch.manual_seed(3)
+    rs = np.random.RandomState(3)
+    S, T = 37, 5
+    coords = rs.uniform(0, 1, (S, 2)).astype(np.float32)
+    for q in (1, 5):
+        m = STInterpMLP(p=0, k_spatial_centers=[9, 25], k_temporal_centers=[4], hidden_dims=[32, 16], dropout=0.1,
+                        layernorm=True, output_dim=q)
+        m.train()
+        got = predict_all_times(m, coords, T)
+        assert m.training                                   # the mode is restored
+        assert got.shape == (T, S) and got.dtype == np.float64
+        m.eval()
+        with torch.no_grad():
+            for ti in range(T):
+                ref = m(torch.zeros(S, 0), torch.from_numpy(coords), torch.full((S, 1), ti / (T - 1))).numpy()
+                np.testing.assert_array_equal(got[ti], ref[:, q // 2].astype(np.float64))
+        one = predict_all_times(m, coords, 1)               # T == 1: t = 0.0
+        with torch.no_grad():
+            ref0 = m(torch.zeros(S, 0), torch.from_numpy(coords), torch.zeros(S, 1)).numpy()
+        np.testing.assert_array_equal(one[0], ref0[:, q // 2].astype(np.float64))
+    z = rs.standard_normal((T, S))
+    z[0, 3] = np.nan
+    masks = [rs.uniform(size=(T, S)) < p for p in (0.6, 0.2, 0.2)]
+    path = save_predictions_npz(tmp_path / "run", got, z, coords, *masks)
+    with np.load(path) as f:
+        assert tuple(f.files) == NPZ_KEYS
+        np.testing.assert_array_equal(f["predictions"], got)
+        np.testing.assert_array_equal(f["true"], z)
+        np.testing.assert_array_equal(f["coords"], coords)
+        for k, mk in zip(NPZ_KEYS[3:], masks):
+            assert f[k].dtype == np.bool_
+            np.testing.assert_array_equal(f[k], mk)
+    with pytest.raises(ValueError):
+        save_predictions_npz(tmp_path / "bad", got, z[:, :-1], coords, *masks)
+    with pytest.raises(ValueError):
+        predict_all_times(STInterpMLP(p=2, k_spatial_centers=[9], k_temporal_centers=[4], hidden_dims=[16]), coords, T)

@@ -689,3 +689,29 @@ def test_quantile_step_on_large_row_tiles(B):
             ref = ref.T                                   # the engine keeps W0 (and dW0) transposed
         err = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
         assert err <= 2e-5, (n, err)
+
+
+# ------------------------------------------------------------------ dense-grid predictions (the driver's A10 caller)
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [1, 5])
+def test_predict_all_times_matches_the_per_slice_loop(q):
+    """stnf.utils.predictions.predict_all_times (one site x time grid call) against the reference driver's loop of
+    one model call per time slice (scripts/train_st_interp.py:1228-1248), median column for multi-quantile models."""
+    from stnf.models import STInterpMLP
+    from stnf.utils.predictions import predict_all_times
+    d = torch.device("cuda", 0)
+    torch.manual_seed(11 + q)
+    rs = np.random.RandomState(11 + q)
+    S, Tn = 1501, 7
+    coords = rs.uniform(-0.02, 1.02, (S, 2)).astype(np.float32)
+    m = STInterpMLP(p=0, k_spatial_centers=[1024, 4096], k_temporal_centers=[10, 15], hidden_dims=[256, 256, 128],
+                    dropout=0.1, layernorm=True, output_dim=q).to(d)
+    m.train()
+    got = predict_all_times(m, coords, Tn)
+    assert m.training and got.shape == (Tn, S) and got.dtype == np.float64
+    m.eval()
+    c = torch.from_numpy(coords).to(d)
+    with torch.no_grad():
+        for ti in range(Tn):
+            ref = m(torch.zeros(S, 0, device=d), c, torch.full((S, 1), ti / (Tn - 1), device=d)).cpu().numpy()
+            assert np.abs(got[ti] - ref[:, q // 2]).max() <= 2e-6 * max(1.0, np.abs(ref).max())
