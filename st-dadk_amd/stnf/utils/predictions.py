@@ -60,3 +60,50 @@ def save_predictions_npz(output_dir, predictions, true, coords, train_mask, vali
     path = os.path.join(str(output_dir), "predictions.npz")
     np.savez(path, **arrs)
     return path
+
+
+@torch.no_grad()
+def evaluate_model(model, dataset, config=None, predictor=None):
+    """The driver's `evaluate_model` (scripts/train_st_interp.py:884-961) on a `DeviceDataset` (or any object with
+    `.coords (N,2)`, `.t (N,1)`, `.y (N,1)`): predictions of the whole set under eval(), then on the host, in the
+    reference's float32 numpy arithmetic: 'mse', 'mae', 'rmse' (of the median column for 'multi-quantile'), plus
+    'check_loss' for `regression_type == 'quantile'` with `current_quantile`, and 'crps', 'mean_check_loss' and the
+    'check_loss' alias for 'multi-quantile'.  The reference walks a DataLoader in batches of min(max(16 B, 32768), N)
+    (:2292-2293); the predictions do not depend on the batching, so the set goes through `Predictor.predict` in
+    its own chunks (device models) or one forward (host models).  `predictor`: reuse one across calls."""
+    from ..losses import check_loss_numpy, compute_crps_multi_quantile      # host arithmetic (the predictions are small)
+    dev = next(model.parameters()).device
+    was_training = model.training
+    model.eval()
+    try:
+        if dev.type == "cuda":
+            if predictor is None:
+                from ..engine import Predictor
+                predictor = Predictor(model)
+            preds_t = predictor.predict(dataset.coords, dataset.t)
+        else:
+            n = dataset.coords.shape[0]
+            preds_t = model(torch.zeros(n, 0), dataset.coords, dataset.t.view(-1, 1))
+    finally:
+        model.train(was_training)
+    preds = preds_t.float().cpu().numpy()                       # (N, 1) or (N, Q)
+    trues = dataset.y.float().cpu().numpy().reshape(-1, 1)      # (N, 1)
+    regression_type = config.get("regression_type", "mean") if config is not None else "mean"
+    if regression_type == "multi-quantile":
+        quantile_levels = config.get("quantile_levels", [0.1, 0.5, 0.9])
+        median_idx = len(quantile_levels) // 2
+        preds_for_metrics = preds[:, median_idx:median_idx + 1]
+    else:
+        preds_for_metrics = preds
+    mse = np.mean((preds_for_metrics - trues) ** 2)
+    mae = np.mean(np.abs(preds_for_metrics - trues))
+    metrics = {"mse": float(mse), "mae": float(mae), "rmse": float(np.sqrt(mse))}
+    if config is not None and config.get("regression_type") == "quantile" and "current_quantile" in config:
+        metrics["check_loss"] = float(check_loss_numpy(preds, trues, config["current_quantile"]))
+    if config is not None and config.get("regression_type") == "multi-quantile":
+        quantile_levels = config.get("quantile_levels", [0.1, 0.5, 0.9])
+        metrics["crps"] = float(compute_crps_multi_quantile(preds, trues, quantile_levels))
+        check_losses = [check_loss_numpy(preds[:, i:i + 1], trues, q) for i, q in enumerate(quantile_levels)]
+        metrics["mean_check_loss"] = float(np.mean(check_losses))
+        metrics["check_loss"] = float(np.mean(check_losses))      # alias, as in the reference
+    return metrics

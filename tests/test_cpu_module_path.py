@@ -190,3 +190,48 @@ def test_predict_all_times_host_and_npz_record(tmp_path):
         save_predictions_npz(tmp_path / "bad", got, z[:, :-1], coords, *masks)
     with pytest.raises(ValueError):
         predict_all_times(STInterpMLP(p=2, k_spatial_centers=[9], k_temporal_centers=[4], hidden_dims=[16]), coords, T)
+
+
+def test_evaluate_model_metrics_host():
+    """stnf.utils.predictions.evaluate_model against the formulas of scripts/train_st_interp.py:884-961 written
+    out in numpy: mse / mae / rmse on the median column, the check loss of a single quantile, CRPS = 2 x the mean
+    check loss over the levels (equation 4.6 with uniform weights) and its aliases."""
+    from stnf.dataio.device_dataset import DeviceDataset
+    from stnf.models import STInterpMLP
+    from stnf.utils.predictions import evaluate_model
+    torch.manual_seed(5)
+    rs = np.random.RandomState(5)
+    n = 211
+    ds = DeviceDataset(torch.from_numpy(rs.uniform(0, 1, (n, 2)).astype(np.float32)),
+                       torch.from_numpy(rs.uniform(0, 1, (n, 1)).astype(np.float32)),
+                       torch.from_numpy(rs.standard_normal((n, 1)).astype(np.float32)))
+    taus = [0.05, 0.25, 0.5, 0.75, 0.95]
+
+    def rho(p, y, q):
+        e = y - p
+        return np.mean(np.maximum((q - 1) * e, q * e))
+
+    for q, cfg in ((1, None), (1, dict(regression_type="quantile", current_quantile=0.9)),
+                   (5, dict(regression_type="multi-quantile", quantile_levels=taus))):
+        m = STInterpMLP(p=0, k_spatial_centers=[9, 25], k_temporal_centers=[4], hidden_dims=[32, 16], dropout=0.1,
+                        layernorm=True, output_dim=q)
+        m.train()
+        got = evaluate_model(m, ds, cfg)
+        assert m.training
+        m.eval()
+        with torch.no_grad():
+            pr = m(torch.zeros(n, 0), ds.coords, ds.t).numpy()
+        y = ds.y.numpy()
+        col = pr[:, 2:3] if q == 5 else pr
+        mse = np.mean((col - y) ** 2)
+        assert got["mse"] == pytest.approx(float(mse), rel=1e-6) and got["rmse"] == pytest.approx(float(np.sqrt(mse)), rel=1e-6)
+        assert got["mae"] == pytest.approx(float(np.mean(np.abs(col - y))), rel=1e-6)
+        if cfg is None:
+            assert set(got) == {"mse", "mae", "rmse"}
+        elif q == 1:
+            assert got["check_loss"] == pytest.approx(float(rho(pr, y, 0.9)), rel=1e-6)
+        else:
+            cl = [rho(pr[:, i:i + 1], y, t) for i, t in enumerate(taus)]
+            assert got["mean_check_loss"] == pytest.approx(float(np.mean(cl)), rel=1e-6)
+            assert got["check_loss"] == got["mean_check_loss"]
+            assert got["crps"] == pytest.approx(2.0 * float(np.mean(cl)), rel=1e-6)

@@ -715,3 +715,30 @@ def test_predict_all_times_matches_the_per_slice_loop(q):
         for ti in range(Tn):
             ref = m(torch.zeros(S, 0, device=d), c, torch.full((S, 1), ti / (Tn - 1), device=d)).cpu().numpy()
             assert np.abs(got[ti] - ref[:, q // 2]).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_evaluate_model_on_the_device_equals_the_host_path():
+    """evaluate_model through Predictor on the GPU == the same model evaluated on host tensors (whose forward is
+    pinned to the goldens in tests/test_cpu_module_path.py), for the mean and the multi-quantile metrics."""
+    import copy
+    from stnf.dataio.device_dataset import DeviceDataset
+    from stnf.models import STInterpMLP
+    from stnf.utils.predictions import evaluate_model
+    d = torch.device("cuda", 0)
+    torch.manual_seed(21)
+    rs = np.random.RandomState(21)
+    n = 40000                                   # several tail tiles of 64 rows
+    c = torch.from_numpy(rs.uniform(0, 1, (n, 2)).astype(np.float32))
+    t = torch.from_numpy((rs.randint(0, 100, (n, 1)) / 99.0).astype(np.float32))
+    y = torch.from_numpy(rs.standard_normal((n, 1)).astype(np.float32))
+    taus = [0.1, 0.5, 0.9]
+    for q, cfg in ((1, None), (3, dict(regression_type="multi-quantile", quantile_levels=taus))):
+        mh = STInterpMLP(p=0, k_spatial_centers=[1024, 4096], k_temporal_centers=[10, 15], hidden_dims=[256, 256, 128],
+                         dropout=0.1, layernorm=True, output_dim=q)
+        md = copy.deepcopy(mh).to(d)
+        got = evaluate_model(md, DeviceDataset(c.to(d), t.to(d), y.to(d)), cfg)
+        ref = evaluate_model(mh, DeviceDataset(c, t, y), cfg)
+        assert set(got) == set(ref)
+        for k in ref:
+            assert got[k] == pytest.approx(ref[k], rel=2e-5), k
