@@ -86,24 +86,19 @@ def evaluate_model(model, dataset, config=None, predictor=None):
             preds_t = model(torch.zeros(n, 0), dataset.coords, dataset.t.view(-1, 1))
     finally:
         model.train(was_training)
-    preds = preds_t.float().cpu().numpy()                       # (N, 1) or (N, Q)
-    trues = dataset.y.float().cpu().numpy().reshape(-1, 1)      # (N, 1)
-    regression_type = config.get("regression_type", "mean") if config is not None else "mean"
-    if regression_type == "multi-quantile":
-        quantile_levels = config.get("quantile_levels", [0.1, 0.5, 0.9])
-        median_idx = len(quantile_levels) // 2
-        preds_for_metrics = preds[:, median_idx:median_idx + 1]
-    else:
-        preds_for_metrics = preds
-    mse = np.mean((preds_for_metrics - trues) ** 2)
-    mae = np.mean(np.abs(preds_for_metrics - trues))
-    metrics = {"mse": float(mse), "mae": float(mae), "rmse": float(np.sqrt(mse))}
-    if config is not None and config.get("regression_type") == "quantile" and "current_quantile" in config:
-        metrics["check_loss"] = float(check_loss_numpy(preds, trues, config["current_quantile"]))
-    if config is not None and config.get("regression_type") == "multi-quantile":
-        quantile_levels = config.get("quantile_levels", [0.1, 0.5, 0.9])
-        metrics["crps"] = float(compute_crps_multi_quantile(preds, trues, quantile_levels))
-        check_losses = [check_loss_numpy(preds[:, i:i + 1], trues, q) for i, q in enumerate(quantile_levels)]
-        metrics["mean_check_loss"] = float(np.mean(check_losses))
-        metrics["check_loss"] = float(np.mean(check_losses))      # alias, as in the reference
-    return metrics
+    pred = preds_t.float().cpu().numpy()                        # (N, Q) float32, like the reference's stacked batches
+    obs = dataset.y.float().cpu().numpy().reshape(-1, 1)
+    kind = (config or {}).get("regression_type", "mean")
+    levels = list((config or {}).get("quantile_levels", [0.1, 0.5, 0.9])) if kind == "multi-quantile" else None
+    # point metrics: the single output, or the median level's column of a multi-quantile head
+    point = pred[:, len(levels) // 2:len(levels) // 2 + 1] if levels is not None else pred
+    err = point - obs
+    sq = float(np.mean(err * err))
+    out = {"mse": sq, "mae": float(np.mean(np.abs(err))), "rmse": float(np.sqrt(np.mean(err * err)))}
+    if kind == "quantile" and "current_quantile" in config:
+        out["check_loss"] = float(check_loss_numpy(pred, obs, config["current_quantile"]))
+    if levels is not None:
+        per_level = [float(check_loss_numpy(pred[:, j:j + 1], obs, tau)) for j, tau in enumerate(levels)]
+        out["crps"] = float(compute_crps_multi_quantile(pred, obs, levels))
+        out["mean_check_loss"] = out["check_loss"] = float(np.mean(per_level))      # the reference keeps both names
+    return out
