@@ -348,3 +348,52 @@ def test_public_header_is_plain_c():
             pytest.skip(f"{cc} not available")
         r = subprocess.run([cc, *args, "-fsyntax-only", "-Wall", "-Werror", hdr], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+# ------------------------------------------------------------------ bench.py: the record's host-side arithmetic
+def test_bench_record_helpers(tmp_path, monkeypatch):
+    """What bench.py prints is priced by these: SURVEY.md 8(d)'s per-observation figures, the whole-step floors,
+    and the provenance gate of `roofline.traffic` (a PMC figure is quoted only for the workload / batch / dtype /
+    kernel sources it was measured on)."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    H, Kt, D, B = [256, 256, 128], 70, 10374, 4096
+    # SURVEY.md 8(d): 41 508 B per observation for the materialised features of C2
+    kind, amount, unit = bench.kernel_work("rbf_build_kernel<4, 0>", B, D, H, 0, 0, Kt)
+    assert (kind, unit) == ("hbm", "B") and amount == B * 41508
+    # AdamW + EMA: five reads and four writes of 4 B per parameter
+    assert bench.kernel_work("adamw_ema_kernel", B, D, H, 1000, 0, Kt) == ("hbm", 36000.0, "B")
+    # the fused step kernel: forward and backward of the layers after the first + layer 0 on its non-zero pairs
+    nnz = 57 * B
+    tail = 2.0 * B * (256 * 256 + 128 * 256 + 128)
+    kind, amount, _ = bench.kernel_work("l1_tail_kernel<4, true, 0, false, false>", B, D, H, 0, nnz, Kt)
+    assert kind == "mfma" and amount == 2.0 * tail + 2.0 * (nnz + B * Kt) * 256
+    assert bench.kernel_work("tail_fwd_bwd_kernel<16, 4, false, false>", B, D, H, 0, nnz, Kt)[1] == 2.0 * tail
+    assert bench.kernel_work("some_other_kernel", B, D, H, 0, nnz, Kt) is None
+    fl = bench.step_floors(B, H, Kt, 1, 2_756_097, 57.0)
+    assert fl["hbm_bytes"] == 40.0 * 2_756_097 + B * (16.0 + 24.0 * 640)
+    assert abs(fl["hbm_us"] - fl["hbm_bytes"] / 8e12 * 1e6) < 1e-9 and abs(fl["mfma_us"] - fl["flops"] / 157.3e12 * 1e6) < 1e-9
+    # provenance gate, on a scratch copy of the tree layout
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles"); os.makedirs(tmp_path / "st-dadk_amd" / "csrc")
+    (tmp_path / "st-dadk_amd" / "csrc" / "k.hip").write_text("// kernel v1\n")
+    assert bench.pmc_traffic("l1_tail_kernel", "c2", B, "f32")[0] is None          # no file
+    sha = bench.csrc_hash()
+    rec = dict(source=dict(workload="c2", batch=B, dtype="f32", commit="abc", csrc_sha16=sha),
+               kernels={"l1_tail_kernel": 68.0e6, "rbf_build_kernel@100": 1.0, "rbf_build_kernel@200": 2.0},
+               kernel_names={"l1_tail_kernel": "l1_tail_kernel<4, true, 0, false, false>"})
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(rec))
+    val, src = bench.pmc_traffic("l1_tail_kernel(stdadk::", "c2", B, "f32")
+    assert val == 68.0e6 and src["commit"] == "abc" and src["kernel"].startswith("l1_tail_kernel<4")
+    assert bench.pmc_traffic("rbf_build_kernel", "c2", B, "f32", 200)[0] == 2.0
+    assert bench.pmc_traffic("rbf_build_kernel", "c2", B, "f32", 300)[0] is None        # no entry for that grid
+    for kw in (dict(workload="c4"), dict(B=8192), dict(dtype="bf16")):
+        args = dict(workload="c2", B=B, dtype="f32"); args.update(kw)
+        v, why = bench.pmc_traffic("l1_tail_kernel", args["workload"], args["B"], args["dtype"])
+        assert v is None and why.startswith("stale")
+    (tmp_path / "st-dadk_amd" / "csrc" / "k.hip").write_text("// kernel v2\n")            # any source change
+    v, why = bench.pmc_traffic("l1_tail_kernel", "c2", B, "f32")
+    assert v is None and "csrc_sha16" in why
