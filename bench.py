@@ -5,10 +5,14 @@
 
 One "step" = one optimisation step on one mini-batch of synthetic KAUST-shaped observations resident
 in HBM: feature build (multi-resolution Wendland + Gaussian bases) -> MLP forward -> MSE -> backward
--> (all-reduce) -> clip + AdamW + EMA.  N > 1 is launched by torch.distributed.run, one rank per GPU,
-observation-sharded with one RCCL all-reduce of the flat gradient per step (weak scaling: per-GPU
-batch fixed).  Rank 0 prints ONE JSON line:
-  value      whole-job observations/s over the K timed steps (max over ranks, barrier-bracketed)
+-> (gradient exchange) -> clip + AdamW + EMA.  N > 1: one rank per GPU over RCCL, observation-sharded (weak
+scaling: per-GPU batch fixed), launched by torch.distributed.run -- or by this script itself: `python bench.py
+--gpus N` with WORLD_SIZE unset starts the N ranks as child processes BEFORE anything touches a GPU and relays
+rank 0's line.  Gradient exchange per step (--dp-mode): `shard` = reduce-scatter + sharded AdamW/EMA + all-gather,
+`allreduce` = one all-reduce + replicated optimiser; the other mode is reported beside the headline.
+Rank 0 prints ONE JSON line:
+  value      whole-job observations/s: the MEDIAN of >= 10 timed windows of K steps each (every window bracketed by
+             barrier + synchronize, max over ranks); min / max of the windows beside it
   roofline   the dominant kernel of the timed step: average launch duration measured live with HIP
              events on the launch stream (stdadk_profile_*), algorithmic bytes/flops per launch
   rbf_build  the standalone materialising feature builder (the "RBF-build GB/s" of BASELINE.json)
@@ -164,11 +168,12 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(wl, batch, dropout, budget_s=20.0):
+def cpu_baseline(wl, batch, dropout, budget_s=12.0, cores=None):
     """The oracle's torch-CPU port of the reference batch body, timed on this box's host cores on a
-    bounded sample (a few steps of the same batch size)."""
+    bounded sample (a few steps of the same batch size) with `cores` torch threads (default: all this process
+    may use)."""
     from oracle import torch_port as tp
-    cores = host_cores()
+    cores = host_cores() if cores is None else max(1, min(int(cores), host_cores()))
     torch.set_num_threads(cores)
     cfg = dict(p=0, k_spatial_centers=wl["k_spatial_centers"], k_temporal_centers=wl["k_temporal_centers"],
                hidden_dims=wl["hidden_dims"], layernorm=True, dropout=dropout, basis="wendland", output_dim=1)
@@ -229,6 +234,46 @@ def kernel_work(name, B, D, H, P_flat, nnz_pairs, Kt, Q=1):
     return None
 
 
+def self_launch(n, argv, script=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Called before
+    this process has touched a GPU (importing torch does not initialise HIP); the parent never does -- it only waits --
+    and no process is replaced (no exec).  Exit code: 0 when every rank exits 0, else the first failing rank's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0 inherits stdout (its one JSON line is the record); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for o in pending:              # a rank that died leaves its partners waiting in a collective
+                        procs[o].terminate()
+            time.sleep(0.2)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,8 +297,14 @@ def main():
                     help="milliseconds of an unrelated kernel (the standalone feature builder) before the warm-up steps, "
                          "to leave idle clocks; 0 = off")
     ap.add_argument("--no-sweep", action="store_true", help="skip the extra per-GPU batch sizes (N = 1 only)")
+    ap.add_argument("--windows", type=int, default=10,
+                    help="timed windows of --steps steps each; `value` is the median window (>= 1)")
+    ap.add_argument("--dp-mode", default="shard", choices=["shard", "allreduce"],
+                    help="N > 1: gradient exchange of the headline line (the other mode is reported beside it)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,9 +340,11 @@ def main():
     else:
         coords, t, y = synth(n_obs, 2025 + rank, dev)       # each rank owns its shard of observations
     batches_per_epoch = max(n_obs // B, 1)
+    shard = world > 1 and args.dp_mode == "shard"
     eng = TrainStep(model, lr=2e-2, weight_decay=5e-4, grad_clip=10.0,
                     ema_decay=1.0 - 1.0 / (10.0 * batches_per_epoch), max_batch=B,
-                    use_graph=args.graph and world == 1, force_dense=args.dense, dtype=args.dtype)
+                    use_graph=args.graph and world == 1, force_dense=args.dense, dtype=args.dtype,
+                    shard_optimizer=shard)
     perm = torch.randperm(n_obs, device=dev)
 
     def batch(i):
@@ -324,21 +377,29 @@ def main():
             torch.cuda.synchronize()
         del cw_feats
     run(0, args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup, args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = tmax.item()
+    # >= 1 timed windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and reduced
+    # with MAX over ranks; `value` is the median window (a 20-step window is 2.4 ms: one window alone moves by a few
+    # per cent from run to run with the chip's clock state), the fastest and slowest window are reported beside it
+    def timed_window(k0):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(k0, args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = tmax.item()
+        return dt
+    n_win = max(1, args.windows)
+    win_s = [timed_window(args.warmup + w * args.steps) for w in range(n_win)]
+    el = sorted(win_s)[(n_win - 1) // 2]                       # median window (lower median for an even count)
     loss = eng.mean_loss()
 
     # ---- per-kernel device time of the step, live, with HIP events on the launch stream.  Every
@@ -355,8 +416,9 @@ def main():
         eng._enqueue(None, c, tt, yy, B, B * world)
     torch.cuda.synchronize()
     eng.time_allreduce = False
-    allreduce_ms = (sum(e0.elapsed_time(e1) for e0, e1 in eng.allreduce_events) / max(len(eng.allreduce_events), 1)
-                    if world > 1 else None)
+    # the step's collectives (all-reduce, or reduce-scatter + clip-partials all-reduce + all-gather): sum of their
+    # event brackets per step
+    allreduce_ms = (sum(e0.elapsed_time(e1) for e0, e1 in eng.allreduce_events) / n_prof if world > 1 else None)
     eng.allreduce_events = []
     recs = N.profile_collect() if rank == 0 else None      # the step's launches only: collected before anything else runs
     N.profile_enable(False)
@@ -378,9 +440,10 @@ def main():
     # ---- N > 1: the configuration BASELINE names for the 8-GPU run (C4: 4 resolutions, 49 728 knots, 12.85 M
     # parameters = a 51 MB gradient) at the per-GPU batch SURVEY.md 8(e) sizes for it (>= 16 384 rows), beside the
     # headline workload above.  Every rank takes part (the step contains the all-reduce).
-    def weak_line(wname, B4):
-        """One more weak-scaling line at N > 1: workload `wname` at B4 rows per GPU, timed like the headline (barrier +
-        synchronize on both sides, MAX over ranks), plus its all-reduce time.  Every rank takes part."""
+    def weak_line(wname, B4, mode):
+        """One more weak-scaling line at N > 1: workload `wname` at B4 rows per GPU with gradient exchange `mode`,
+        timed like the headline (barrier + synchronize on both sides, MAX over ranks), plus the time of its
+        collectives per step.  Every rank takes part."""
         w4 = WORKLOADS[wname]
         n4 = max(w4["n_obs"] // world, 4 * B4)
         torch.manual_seed(0)
@@ -388,7 +451,8 @@ def main():
                          hidden_dims=w4["hidden_dims"], dropout=args.dropout, layernorm=True).to(dev)
         m4.train()
         c4c, c4t, c4y = synth(n4, 4025 + rank, dev)
-        e4 = TrainStep(m4, lr=2e-2, weight_decay=5e-4, grad_clip=10.0, ema_decay=0.999, max_batch=B4, dtype=args.dtype)
+        e4 = TrainStep(m4, lr=2e-2, weight_decay=5e-4, grad_clip=10.0, ema_decay=0.999, max_batch=B4, dtype=args.dtype,
+                       shard_optimizer=(mode == "shard"))
         perm4 = torch.randperm(n4, device=dev)
         nb4 = n4 // B4
 
@@ -408,12 +472,42 @@ def main():
         e4.time_allreduce = True
         run4(5 + k4, 10)
         torch.cuda.synchronize()
-        ar4 = sum(a0.elapsed_time(a1) for a0, a1 in e4.allreduce_events) / max(len(e4.allreduce_events), 1)
+        ar4 = sum(a0.elapsed_time(a1) for a0, a1 in e4.allreduce_events) / 10
         dist.barrier()
-        return {"workload": w4["name"], "per_gpu_batch": B4, "global_batch": B4 * world, "n_obs_per_gpu": n4,
-                "obs_per_s": world * B4 * k4 / el4.item(), "ms_per_step": el4.item() / k4 * 1e3, "steps": k4,
-                "gradient_bytes": 4 * e4.flat.numel(), "allreduce_ms_per_step": ar4, "scaling": "weak",
-                "dtype": args.dtype}
+        res = {"workload": w4["name"], "per_gpu_batch": B4, "global_batch": B4 * world, "n_obs_per_gpu": n4,
+               "dp_mode": mode, "obs_per_s": world * B4 * k4 / el4.item(), "ms_per_step": el4.item() / k4 * 1e3,
+               "steps": k4, "gradient_bytes": 4 * e4.flat.numel(), "collectives_ms_per_step": ar4, "scaling": "weak",
+               "dtype": args.dtype}
+        del e4, m4, c4c, c4t, c4y, perm4
+        return res
+
+    def c5_sharded_line():
+        """BASELINE config C5 on N GPUs: the 10 M-point prediction grid (100 000 sites x 100 times), sites sharded over
+        the ranks with no collective on the data path, the (T, S_r, Q) blocks all-gathered at the end
+        (stnf.distributed.sharded_predict_grid; replaces the per-slice loop of scripts/train_st_interp.py:1232-1248)."""
+        from stnf.engine import Predictor
+        from stnf import distributed as DD
+        S5, T5 = 100_000, 100
+        g5 = torch.Generator().manual_seed(5)
+        c5 = torch.rand(S5, 2, generator=g5).to(dev)                 # the same sites on every rank
+        tv5 = torch.arange(T5, device=dev, dtype=torch.float32) / (T5 - 1)
+        model.eval()
+        pr = Predictor(model)
+        out = DD.sharded_predict_grid(pr.predict_grid, c5, tv5)      # warm-up (+ first-call attributes)
+        res = {"points": S5 * T5, "sites": S5, "times": T5, "n_gpus": world}
+        for label, fn in (("with_final_allgather", lambda: DD.sharded_predict_grid(pr.predict_grid, c5, tv5)),
+                          ("shards_only", lambda: pr.predict_grid(c5[slice(*DD.shard_range(S5, rank, world))], tv5))):
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                out = fn()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            dt = torch.tensor([(time.perf_counter() - t1) / 3], device=dev, dtype=torch.float64)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            res[label] = {"points_per_s": S5 * T5 / dt.item(), "ms_per_call": dt.item() * 1e3}
+        del out
+        model.train()
+        return res
 
     # ---- N > 1: beside the headline line (the reference's batch of 4096 rows per GPU, where the 11 MB gradient
     # all-reduce is as long as the step), (a) the configuration BASELINE names for the 8-GPU run -- C4: 4 resolutions,
@@ -421,13 +515,22 @@ def main():
     # (>= 16 384 rows), and (b) the headline model at 65 536 rows per GPU, where the same collective is ~10 % of the step
     extra_lines = {}
     if world > 1:
-        for key, wname, bb in (("c4_weak_scaling_line", "c4", max(16384, B)), ("c2_b65536_weak_scaling_line", "c2", 65536)):
-            if wname == args.workload and bb == B:
+        other = "allreduce" if args.dp_mode == "shard" else "shard"
+        jobs = [("other_dp_mode_line", args.workload, B, other),
+                ("c4_weak_scaling_line", "c4", max(16384, B), args.dp_mode),
+                ("c4_weak_scaling_line_other_dp_mode", "c4", max(16384, B), other),
+                ("c2_b65536_weak_scaling_line", "c2", 65536, args.dp_mode)]
+        for key, wname, bb, mode in jobs:
+            if wname == args.workload and bb == B and mode == args.dp_mode:
                 continue
             try:
-                extra_lines[key] = weak_line(wname, bb)
+                extra_lines[key] = weak_line(wname, bb, mode)
             except Exception as e:                      # noqa: BLE001  (the headline line must survive these extras)
                 extra_lines[key] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            extra_lines["inference_c5_10M_sharded"] = c5_sharded_line()
+        except Exception as e:                          # noqa: BLE001
+            extra_lines["inference_c5_10M_sharded"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         agg = {}
         for name, ms in recs:
@@ -504,6 +607,9 @@ def main():
         ms_step = el / args.steps * 1e3
         out = {
             "metric": "train-step samples/sec (obs points/sec)", "value": args.gpus * B * args.steps / el,
+            "value_windows": {"n": n_win, "steps_each": args.steps, "statistic": "median window",
+                              "min": args.gpus * B * args.steps / max(win_s), "max": args.gpus * B * args.steps / min(win_s),
+                              "ms_per_step_each": [round(w / args.steps * 1e3, 5) for w in win_s]},
             "unit": "obs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -518,7 +624,10 @@ def main():
                        "batch_preparation": "pipelined on a side stream" if (eng.uses_window and not args.no_pipeline
                                                                               and not eng.use_graph) else "in the step",
                        "device_warmup_ms_before_warmup_steps": args.clock_warmup_ms,
-                       "parallelism": f"dp{args.gpus}"},
+                       "parallelism": f"dp{args.gpus}",
+                       "gradient_exchange": ("none (one GPU)" if world == 1 else
+                                             ("reduce-scatter + sharded AdamW/EMA + all-gather" if shard
+                                              else "all-reduce + replicated AdamW/EMA"))},
             "roofline": roof,
             "rbf_build": {"bound": "hbm", "achieved": rbf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": rbf_gbs / HBM_PEAK_GBS, "bytes_per_obs": 12 + 4 * D, "avg_launch_us": t_rbf * 1e6,
@@ -542,13 +651,18 @@ def main():
         if world > 1:
             # the one collective of the path, timed with events around it on the step's stream (rank 0's view;
             # it includes waiting for the slowest rank to arrive)
-            out["allreduce"] = {"ms_per_step": allreduce_ms, "gradient_bytes": 4 * P_flat,
-                                "algorithm_bandwidth_GBs": 4 * P_flat / (allreduce_ms * 1e-3) / 1e9 if allreduce_ms else None}
+            out["collectives"] = {"dp_mode": args.dp_mode, "ms_per_step": allreduce_ms, "gradient_bytes": 4 * P_flat,
+                                  "algorithm_bandwidth_GBs": 4 * P_flat / (allreduce_ms * 1e-3) / 1e9 if allreduce_ms else None,
+                                  "note": "event brackets on the step's stream around every collective of a step (rank 0: "
+                                          "includes waiting for the slowest rank)"}
             out.update(extra_lines)
         if args.gpus == 1 and not args.no_sweep:
-            def timed(b2, k2, model_kw=None, eng_kw=None, graph=None):
-                """obs/s of the same fused step for another batch size / objective / knot mode."""
+            def timed(b2, k2, model_kw=None, eng_kw=None, graph=None, data=None):
+                """obs/s of the same fused step for another batch size / objective / knot mode (`data`: another
+                resident observation set (coords, t, y, perm) instead of the headline's)."""
                 torch.manual_seed(0)
+                coords_, t_, y_, perm_ = data if data is not None else (coords, t, y, perm)
+                n_obs_ = coords_.shape[0]
                 mk = dict(p=0, k_spatial_centers=wl["k_spatial_centers"],
                           k_temporal_centers=wl["k_temporal_centers"], hidden_dims=wl["hidden_dims"],
                           dropout=args.dropout, layernorm=True)
@@ -557,16 +671,16 @@ def main():
                 m2.train()
                 e2 = TrainStep(m2, lr=2e-2, weight_decay=5e-4, grad_clip=10.0, ema_decay=0.999, max_batch=b2,
                                use_graph=args.graph if graph is None else graph, **(eng_kw or {}))
-                nb2 = max(n_obs // b2, 1)
+                nb2 = max(n_obs_ // b2, 1)
                 def sl(i):
-                    return perm[(i % nb2) * b2:(i % nb2) * b2 + b2]
+                    return perm_[(i % nb2) * b2:(i % nb2) * b2 + b2]
                 pipe = not args.no_pipeline
                 for i in range(5):
-                    e2.step_indexed(coords, t, y, sl(i), next_idx=sl(i + 1) if pipe else None)
+                    e2.step_indexed(coords_, t_, y_, sl(i), next_idx=sl(i + 1) if pipe else None)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for i in range(5, 5 + k2):
-                    e2.step_indexed(coords, t, y, sl(i), next_idx=sl(i + 1) if pipe else None)
+                    e2.step_indexed(coords_, t_, y_, sl(i), next_idx=sl(i + 1) if pipe else None)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
                 res = {"obs_per_s": b2 * k2 / dt, "ms_per_step": dt / k2 * 1e3,
@@ -584,10 +698,27 @@ def main():
                                    "tests/test_gpu_bf16.py (emulation of the operand rounding + float64 goldens)",
                                    **{str(b2): timed(b2, 40 if b2 > B else 100, eng_kw=dict(dtype="bf16"))
                                       for b2 in (B, 16384, 65536) if b2 <= n_obs}}
+            # the north_star's wording, "1M-point / 3-resolution-basis config at 1 GPU": BASELINE config C3's shape
+            # (KAUST 2b: 10 000 sites x 100 times = 1 M rows resident in HBM, 3-resolution basis) at the same batch,
+            # fp32 and with bf16 operands after layer 0; same per-step work as the headline, another gather footprint
+            if args.workload != "c3":
+                w3 = WORKLOADS["c3"]
+                d3 = synth_sites(w3["sites"], w3["times"], 2025, dev)
+                d3 = d3 + (torch.randperm(d3[0].shape[0], device=dev),)
+                mk3 = dict(k_spatial_centers=w3["k_spatial_centers"], k_temporal_centers=w3["k_temporal_centers"],
+                           hidden_dims=w3["hidden_dims"])
+                c3v = {"workload": w3["name"], "rows_resident": int(d3[0].shape[0]), "per_gpu_batch": B,
+                       "f32": timed(B, 200, mk3, data=d3), "bf16": timed(B, 200, mk3, dict(dtype="bf16"), data=d3)}
+                del d3
+            else:
+                c3v = None
             # the "next" rows of SURVEY.md §8(f) on the same workload and batch: multi-quantile objectives
             # (N3) and learnable knots (N2, materialising path); reported beside, never as, `value`
             taus = [0.05, 0.25, 0.5, 0.75, 0.95]
             out["variants"] = {
+                **({"c3_1M_rows_f32": dict(c3v["f32"], workload=c3v["workload"], rows_resident=c3v["rows_resident"]),
+                    "c3_1M_rows_bf16": dict(c3v["bf16"], workload=c3v["workload"], rows_resident=c3v["rows_resident"],
+                                            dtype="bf16 operands after layer 0, f32 accumulate")} if c3v else {}),
                 "multi_quantile_q5_noncrossing": timed(B, 60, dict(output_dim=5), dict(
                     loss="pinball", quantile_levels=taus, non_crossing_weight=0.5)),
                 "multi_quantile_q5_delta_head": timed(B, 60, dict(output_dim=5, use_delta_reparameterization=True),
@@ -682,7 +813,10 @@ def main():
             out["variants"]["inference_c5_10M"] = c5_res
             model.train()
         if args.gpus == 1 and not args.no_cpu_baseline:
+            # the reference's CPU path at all host cores this process may use AND at 8 threads
             out["cpu_baseline"] = cpu_baseline(wl, B, args.dropout)
+            if out["cpu_baseline"]["cores"] != 8:
+                out["cpu_baseline_8_threads"] = cpu_baseline(wl, B, args.dropout, cores=8)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

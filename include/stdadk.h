@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STDADK_ABI_VERSION 6
+#define STDADK_ABI_VERSION 7
 #define STDADK_MAX_HIDDEN 8
 #define STDADK_MAX_LEVELS 8
 #define STDADK_SUMSQ_PARTS 256 /* partial sums written by stdadk_sumsq_f32 */
@@ -206,11 +206,19 @@ int stdadk_bf16_shadow_refresh(const float *p, const stdadk_bf16_shadow *shadow,
 
 int stdadk_step_advance(int32_t *step_dev, stdadk_stream_t stream);
 
+/* Non-finite guard (ABI 7; scripts/train_st_interp.py:724-733 leaves the epoch at the first batch whose loss is NaN).
+ * `loss_watch` is the running objective accumulator the step's kernels add into (the loss_sum of the step-level entry
+ * points), `nonfinite_step` a device int32 that starts at 0: the optimiser launch of a step -- which runs after the
+ * step's last addition to the accumulator -- stores the 1-based number of the step it applies there when the
+ * accumulator is not finite and the word is still 0.  A running sum stays non-finite once it is, so the word ends up
+ * holding the FIRST step whose objective was not finite; the host reads it when it reads the loss (no extra sync per
+ * step).  Both NULL = off. */
 int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
                          float lr, const float *lr_dev, float beta1, float beta2, float eps,
                          float weight_decay, int32_t step, const int32_t *step_dev, float max_norm,
                          const float *sumsq_parts, int32_t n_parts, float grad_mul, float ema_decay,
-                         const stdadk_bf16_shadow *shadow, stdadk_stream_t stream);
+                         const stdadk_bf16_shadow *shadow, const float *loss_watch, int32_t *nonfinite_step,
+                         stdadk_stream_t stream);
 
 /* A9 with two parameter groups in one launch each (learnable knots: the MLP parameters and the knot
  * tensors are clipped on their own norms and stepped with their own learning rates,
@@ -233,7 +241,7 @@ int stdadk_sumsq2_f32(const float *g0, int64_t n0, float *parts0, const float *g
 int stdadk_adamw_ema2_f32(const stdadk_adam_group *g0, const stdadk_adam_group *g1, float beta1,
                           float beta2, float eps, float weight_decay, int32_t step,
                           const int32_t *step_dev, float grad_mul, float ema_decay,
-                          stdadk_stream_t stream);
+                          const float *loss_watch, int32_t *nonfinite_step, stdadk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Step-level entry points: observations in, predictions / gradients out.
@@ -442,6 +450,7 @@ typedef struct stdadk_optim_desc {
   float *sumsq_parts;           /* [STDADK_GRADSQ_PARTS] device scratch                            */
   float ema_decay;
   const stdadk_bf16_shadow *shadow;   /* bf16 operand copies to keep current (NULL = none)           */
+  int32_t *nonfinite_step;      /* non-finite guard on the call's loss_sum (see stdadk_adamw_ema_f32), or NULL */
 } stdadk_optim_desc;
 int stdadk_train_step_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
                           const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,

@@ -53,10 +53,29 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 
 constexpr int kWave = 64;
 
+// Sum over the 64 lanes of a wave, the same value in every lane.  Data-parallel primitives (DPP) inside the rows of
+// 16 lanes -- quad swaps, then the half-row and row mirrors: four v_add_f32_dpp, no LDS crossbar -- then the row sums
+// chained over the four rows (row_bcast15 / row_bcast31) and lane 63 read back through an SGPR.  The butterfly through
+// ds_bpermute (__shfl_xor) this replaces was six dependent LDS round trips per sum: at one row per wave the two sums of
+// a LayerNorm phase were ~40 % of the phase.  Fixed summation tree: ((quad pairs) half-rows) rows, (r0+r1)+(r2+r3).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef STDADK_SHFL_SUM      // the butterfly through the LDS crossbar (kept for A/B measurements)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#else
+  v += dpp_f32<0xB1>(v);            // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_f32<0x4E>(v);            // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_f32<0x141>(v);           // row_half_mirror: the other quad of the 8
+  v += dpp_f32<0x140>(v);           // row_mirror: the other half of the 16 -> every lane holds its row's sum
+  v += dpp_f32<0x142, 0xA>(v);      // row_bcast15 into rows 1 and 3: r0 + r1, r2 + r3
+  v += dpp_f32<0x143, 0xC>(v);      // row_bcast31 into rows 2 and 3: row 3 = (r0 + r1) + (r2 + r3)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
 
 // Counter-based keep-mask generator for dropout: one 32-bit hash per (seed, layer, element).

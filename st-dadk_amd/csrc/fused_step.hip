@@ -61,9 +61,13 @@ static int launch(const L1FwdArgs &l, const TailFwdArgs &f, const TailBwdArgs &b
 
 bool l1_tail_supported(int64_t B, int H) { return B <= 16 * 256 && (H == 256 || H == 128); }
 
-int l1_tail_launch(const L1FwdArgs &l_in, int basis, bool ln, const TailFwdArgs &f, const TailBwdArgs &b,
+int l1_tail_launch(const L1FwdArgs &l_in, int basis, bool ln, const TailFwdArgs &f_in, const TailBwdArgs &b_in,
                    hipStream_t st) {
   L1FwdArgs l = l_in;
+  TailFwdArgs f = f_in;
+  TailBwdArgs b = b_in;
+  f.krot = b.krot = tail_krot();
+  f.stagger_ticks = 0;
   STDADK_REQUIRE(l1_tail_supported(l.B, l.H) && f.B == l.B && b.B == l.B, STDADK_E_ARG,
                  "l1_tail: needs B <= 4096 and H in {128, 256}");
   STDADK_REQUIRE((int64_t)(l.g.p + l.g.Ks + l.g.Kt) * l.H < (1ll << 32), STDADK_E_ARG,

@@ -1599,7 +1599,8 @@ extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_ml
   }
   return stdadk_adamw_ema_f32(o->p, o->g, o->m, o->v, o->ema, o->n, o->lr, o->lr_dev, o->beta1, o->beta2, o->eps,
                               o->weight_decay, 1, o->step_dev, o->max_norm, clip ? o->sumsq_parts : nullptr, n_parts,
-                              1.0f, o->ema_decay, o->shadow, stream);
+                              1.0f, o->ema_decay, o->shadow, o->nonfinite_step ? loss_sum : nullptr, o->nonfinite_step,
+                              stream);
 }
 
 extern "C" int stdadk_bin_batch_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,

@@ -63,6 +63,7 @@ struct AdamArgs {
   float beta1, beta2, eps, wd;
   int step; const int *step_dev;
   float max_norm; const float *sumsq; int n_parts; float grad_mul; float ema_decay;
+  const float *watch; int *bad_step;      // non-finite guard (stdadk.h): NULL = off
   ShadowArgs sh;
 };
 
@@ -158,6 +159,13 @@ __device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int blo
   }
   const float lr = a.lr_dev ? a.lr_dev[0] : a.lr;
   const int step = a.step_dev ? a.step_dev[0] : a.step;
+  // non-finite guard: the objective accumulator is a running sum, so the first step that leaves it non-finite is the
+  // first step whose batch objective was (scripts/train_st_interp.py:724-733 stops the epoch there); one thread of
+  // the launch, launches of a stream run in order: no atomics
+  if (a.bad_step && block == 0 && threadIdx.x == 0) {
+    const float l = a.watch[0];
+    if (!(fabsf(l) <= 3.402823466e38f) && a.bad_step[0] == 0) a.bad_step[0] = step;
+  }
   float coef = 1.f;
   if (a.max_norm > 0.f && a.sumsq) {
     // block-wide sum of the partials, same order in every block (L2-resident, a few hundred floats)
@@ -270,8 +278,10 @@ extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v
                                     float weight_decay, int32_t step, const int32_t *step_dev, float max_norm,
                                     const float *sumsq_parts, int32_t n_parts, float grad_mul,
                                     float ema_decay, const stdadk_bf16_shadow *shadow,
-                                    stdadk_stream_t stream) {
+                                    const float *loss_watch, int32_t *nonfinite_step, stdadk_stream_t stream) {
   STDADK_REQUIRE(n >= 0, STDADK_E_ARG, "adamw: negative n");
+  STDADK_REQUIRE((loss_watch != nullptr) == (nonfinite_step != nullptr), STDADK_E_ARG,
+                 "adamw: loss_watch and nonfinite_step go together (both or neither)");
   if (n == 0) return 0;
   STDADK_REQUIRE(p && g && m && v, STDADK_E_ARG, "adamw: NULL pointer");
   STDADK_REQUIRE(step_dev || step >= 1, STDADK_E_ARG, "adamw: step must be >= 1");
@@ -280,6 +290,7 @@ extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v
   a.p = p; a.g = g; a.m = m; a.v = v; a.ema = ema; a.n = n; a.lr = lr; a.lr_dev = lr_dev;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.step = step; a.step_dev = step_dev;
   a.max_norm = max_norm; a.sumsq = sumsq_parts; a.n_parts = n_parts; a.grad_mul = grad_mul; a.ema_decay = ema_decay;
+  a.watch = loss_watch; a.bad_step = nonfinite_step;
   if (int rc = fill_shadow(a.sh, shadow, p, n)) return rc;
   STDADK_REQUIRE(a.sh.n == 0 || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                                   reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(ema)) & 15) == 0,
@@ -304,6 +315,7 @@ static int fill_group(AdamArgs &a, const stdadk_adam_group *gr, float beta1, flo
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.step = step; a.step_dev = step_dev;
   a.max_norm = gr->max_norm; a.sumsq = gr->sumsq_parts; a.n_parts = gr->n_parts; a.grad_mul = grad_mul;
   a.ema_decay = ema_decay;
+  a.watch = nullptr; a.bad_step = nullptr;
   if (int rc = fill_shadow(a.sh, gr->shadow, gr->p, gr->n)) return rc;
   STDADK_REQUIRE(a.sh.n == 0 || ((reinterpret_cast<uintptr_t>(gr->g) | reinterpret_cast<uintptr_t>(gr->m) |
                                   reinterpret_cast<uintptr_t>(gr->v) | reinterpret_cast<uintptr_t>(gr->ema)) & 15) == 0,
@@ -326,13 +338,16 @@ extern "C" int stdadk_bf16_shadow_refresh(const float *p, const stdadk_bf16_shad
 extern "C" int stdadk_adamw_ema2_f32(const stdadk_adam_group *g0, const stdadk_adam_group *g1, float beta1,
                                      float beta2, float eps, float weight_decay, int32_t step,
                                      const int32_t *step_dev, float grad_mul, float ema_decay,
-                                     stdadk_stream_t stream) {
+                                     const float *loss_watch, int32_t *nonfinite_step, stdadk_stream_t stream) {
   STDADK_REQUIRE(step_dev || step >= 1, STDADK_E_ARG, "adamw2: step must be >= 1");
+  STDADK_REQUIRE((loss_watch != nullptr) == (nonfinite_step != nullptr), STDADK_E_ARG,
+                 "adamw2: loss_watch and nonfinite_step go together (both or neither)");
   AdamArgs a0, a1;
   int rc = fill_group(a0, g0, beta1, beta2, eps, weight_decay, step, step_dev, grad_mul, ema_decay);
   if (rc) return rc;
   rc = fill_group(a1, g1, beta1, beta2, eps, weight_decay, step, step_dev, grad_mul, ema_decay);
   if (rc) return rc;
+  a0.watch = loss_watch; a0.bad_step = nonfinite_step;        // group 0's first block keeps the guard
   int64_t nb0 = ceil_div(a0.n, 256 * 4), nb1 = ceil_div(a1.n, 256 * 4);
   if (nb0 > 1536) nb0 = 1536;        // one resident round of the chip (see stdadk_adamw_ema_f32)
   if (nb1 > 1536) nb1 = 1536;

@@ -71,6 +71,9 @@ struct TailFwdArgs {
   uint64_t seed;
   const int *step_dev;
   int bf16;                     // STDADK_FLAG_BF16: the layers' GEMMs take bf16 operands (L[i].Wbf)
+  int krot;                     // per-workgroup rotation of the K-chunk order (set by the launch code, tail_krot())
+  int stagger_ticks;            // 512-thread workgroups, two per CU: the later-placed one of the first round waits this
+                                // many 100 MHz ticks before it starts (set by the launch code; 0 = off)
   unsigned long long *stamps;   // -DSTDADK_DIAG builds only: [blocks][16] wall-clock stamps (100 MHz), else NULL
 };
 
@@ -91,10 +94,16 @@ struct TailBwdArgs {
   uint64_t seed;
   const int *step_dev;
   int bf16;                     // STDADK_FLAG_BF16: dA = dZ W with bf16 operands (L[i].WTbf)
+  int krot;                     // as in TailFwdArgs
   unsigned long long *stamps;   // -DSTDADK_DIAG builds only (see TailFwdArgs), else NULL
 };
 
 bool tail_supported(const stdadk_mlp_desc *d, int first_layer);
+// 1 with STDADK_KROT=1 (measurement aid, off by default): workgroups of a launch walk the K chunks of the shared
+// weights from different starting chunks (tail_body.h: chunk_start).  Measured in round 3 at no gain (the GEMM phases
+// of the 16-row tiles 6.92 vs 7.12 us, the fused kernel 57.56 vs 57.64 us in-kernel: DESIGN.md section 8) -- the CUs
+// of an XCD asking for the same lines at the same time is not what paces those phases.
+int tail_krot();
 // rows per workgroup the launches will use for a batch of B rows (`cap32`: bf16 operands together with the dense
 // layer 0 inside the launch keep three activation images in LDS, which fit for at most 32 rows)
 int tail_rows(int64_t B, bool cap32 = false);

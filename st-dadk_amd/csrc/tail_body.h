@@ -131,14 +131,22 @@ static __device__ __forceinline__ void mma_chunk(f32x4 (*acc)[MAX_NI], const BFr
   }
 }
 
+// Every workgroup of a launch multiplies by the SAME weights; walking the K chunks in the same order, the 32 CUs of an
+// XCD ask its L2 for the same 128-byte lines at the same moment.  With STDADK_KROT=1 a workgroup starts its walk at
+// chunk `rot mod nchunk` and wraps around, so that at any instant the CUs of an XCD are spread over the chunks, i.e.
+// over different lines / channels; only the order of a tile's fp32 partial sums changes.  Measured (round 3, VERDICT
+// r2 item 3): no gain -- off by default (rot = 0 is the natural order), kept as a switch for that measurement.
+static __device__ __forceinline__ int chunk_start(int rot, int nchunk) { return rot % nchunk; }
+
 // The first 32-deep weight chunk of a GEMM phase, requested one phase EARLY (before the row-local
 // LayerNorm / input phase that precedes the GEMM) so that its L2 round trip is hidden behind that phase.
+// `rot`: this workgroup's rotation of the K-chunk order (chunk_start above), 0 = natural order.
 template <bool KN = false>
 static __device__ __forceinline__ void preload_w(BFrag<MAX_NI> &f, const float *__restrict__ W, int N, int K,
-                                                 int wave, int c16, int q) {
+                                                 int wave, int c16, int q, int rot = 0) {
   // always all MAX_NI tiles (a tile the layer does not have is a clamped, unused load): one write pattern for the
   // fragment whatever the layer's width keeps it in registers
-  if (wave < (N >> 4)) load_bfrag<MAX_NI, KN>(f, W, N, K, 0, wave, c16, q);
+  if (wave < (N >> 4)) load_bfrag<MAX_NI, KN>(f, W, N, K, chunk_start(rot, (K + 31) >> 5), wave, c16, q);
 }
 
 // GEMM of a phase: acc[mt][i] (rows 16 mt.., N tile wave + NW*i) += A[R x K] (LDS, row stride ACT_LD) * W.
@@ -148,25 +156,29 @@ static __device__ __forceinline__ void preload_w(BFrag<MAX_NI> &f, const float *
 template <int MT, int NI, bool KN>
 static __device__ __forceinline__ void gemm16_loop(f32x4 (*acc)[MAX_NI], const float *__restrict__ A,
                                                    const float *__restrict__ W, int N, int K, int wave, int c16,
-                                                   int q, BFrag<MAX_NI> &f0) {
+                                                   int q, BFrag<MAX_NI> &f0, int rot) {
   const int nchunk = (K + 31) >> 5;
   BFrag<MAX_NI> f1;
-  for (int c = 0; c < nchunk; c += 2) {
-    if (c + 1 < nchunk) load_bfrag<NI, KN>(f1, W, N, K, c + 1, wave, c16, q);
+  int c = chunk_start(rot, nchunk);             // f0 holds this chunk (preload_w)
+  for (int i = 0; i < nchunk; i += 2) {
+    const int c1 = c + 1 == nchunk ? 0 : c + 1;
+    if (i + 1 < nchunk) load_bfrag<NI, KN>(f1, W, N, K, c1, wave, c16, q);
     mma_chunk<NI, MT>(acc, f0, A, K, c, c16, q);
-    if (c + 1 < nchunk) {
-      if (c + 2 < nchunk) load_bfrag<NI, KN>(f0, W, N, K, c + 2, wave, c16, q);
-      mma_chunk<NI, MT>(acc, f1, A, K, c + 1, c16, q);
+    if (i + 1 < nchunk) {
+      const int c2 = c1 + 1 == nchunk ? 0 : c1 + 1;
+      if (i + 2 < nchunk) load_bfrag<NI, KN>(f0, W, N, K, c2, wave, c16, q);
+      mma_chunk<NI, MT>(acc, f1, A, K, c1, c16, q);
+      c = c2;
     }
   }
 }
 template <int MT, bool KN = false>
 static __device__ __forceinline__ void gemm16_pre(f32x4 (*acc)[MAX_NI], const float *__restrict__ A,
                                                   const float *__restrict__ W, int N, int K, int wave, int c16,
-                                                  int q, BFrag<MAX_NI> &f0) {
+                                                  int q, BFrag<MAX_NI> &f0, int rot = 0) {
   if (wave >= (N >> 4)) return;                 // scalar: this wave has no N tile in a narrow layer
-  if (MAX_NI > 1 && tiles_of(N) > 1) gemm16_loop<MT, MAX_NI, KN>(acc, A, W, N, K, wave, c16, q, f0);
-  else gemm16_loop<MT, 1, KN>(acc, A, W, N, K, wave, c16, q, f0);
+  if (MAX_NI > 1 && tiles_of(N) > 1) gemm16_loop<MT, MAX_NI, KN>(acc, A, W, N, K, wave, c16, q, f0, rot);
+  else gemm16_loop<MT, 1, KN>(acc, A, W, N, K, wave, c16, q, f0, rot);
 }
 
 // ---- bf16 operands
@@ -199,8 +211,8 @@ static __device__ __forceinline__ void mma_chunk_h(f32x4 (*acc)[MAX_NI], const B
 }
 
 static __device__ __forceinline__ void preload_wh(BFragH<MAX_NI> &f, const u16 *__restrict__ Wn, int N, int K, int wave,
-                                                  int c16, int q) {
-  if (wave < (N >> 4)) load_bfrag_h<MAX_NI>(f, Wn, N, K, 0, wave, c16, q);
+                                                  int c16, int q, int rot = 0) {
+  if (wave < (N >> 4)) load_bfrag_h<MAX_NI>(f, Wn, N, K, chunk_start(rot, (K + 63) >> 6), wave, c16, q);
 }
 
 // acc[mt][i] += A[R x K] (bf16 image in LDS, columns K .. 64 ceil(K/64) zero) * W^T, W = [N][K] bf16 in global
@@ -208,25 +220,29 @@ static __device__ __forceinline__ void preload_wh(BFragH<MAX_NI> &f, const u16 *
 template <int MT, int NI>
 static __device__ __forceinline__ void gemm16_loop_h(f32x4 (*acc)[MAX_NI], const u16 *__restrict__ A,
                                                      const u16 *__restrict__ Wn, int N, int K, int wave, int c16, int q,
-                                                     BFragH<MAX_NI> &f0) {
+                                                     BFragH<MAX_NI> &f0, int rot) {
   const int nchunk = (K + 63) >> 6;
   BFragH<MAX_NI> f1;
-  for (int c = 0; c < nchunk; c += 2) {
-    if (c + 1 < nchunk) load_bfrag_h<NI>(f1, Wn, N, K, c + 1, wave, c16, q);
+  int c = chunk_start(rot, nchunk);
+  for (int i = 0; i < nchunk; i += 2) {
+    const int c1 = c + 1 == nchunk ? 0 : c + 1;
+    if (i + 1 < nchunk) load_bfrag_h<NI>(f1, Wn, N, K, c1, wave, c16, q);
     mma_chunk_h<NI, MT>(acc, f0, A, c, c16, q);
-    if (c + 1 < nchunk) {
-      if (c + 2 < nchunk) load_bfrag_h<NI>(f0, Wn, N, K, c + 2, wave, c16, q);
-      mma_chunk_h<NI, MT>(acc, f1, A, c + 1, c16, q);
+    if (i + 1 < nchunk) {
+      const int c2 = c1 + 1 == nchunk ? 0 : c1 + 1;
+      if (i + 2 < nchunk) load_bfrag_h<NI>(f0, Wn, N, K, c2, wave, c16, q);
+      mma_chunk_h<NI, MT>(acc, f1, A, c1, c16, q);
+      c = c2;
     }
   }
 }
 template <int MT>
 static __device__ __forceinline__ void gemm16_pre_h(f32x4 (*acc)[MAX_NI], const u16 *__restrict__ A,
                                                     const u16 *__restrict__ Wn, int N, int K, int wave, int c16, int q,
-                                                    BFragH<MAX_NI> &f0) {
+                                                    BFragH<MAX_NI> &f0, int rot = 0) {
   if (wave >= (N >> 4)) return;
-  if (MAX_NI > 1 && tiles_of(N) > 1) gemm16_loop_h<MT, MAX_NI>(acc, A, Wn, N, K, wave, c16, q, f0);
-  else gemm16_loop_h<MT, 1>(acc, A, Wn, N, K, wave, c16, q, f0);
+  if (MAX_NI > 1 && tiles_of(N) > 1) gemm16_loop_h<MT, MAX_NI>(acc, A, Wn, N, K, wave, c16, q, f0, rot);
+  else gemm16_loop_h<MT, 1>(acc, A, Wn, N, K, wave, c16, q, f0, rot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,6 +331,8 @@ static __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = tile * R;
+  // workgroups b, b + 8, ... share an XCD: consecutive ones of them start their K walks one chunk apart
+  const int rot = a.krot ? (int)(blockIdx.x >> 3) : 0;
   STAMP(0);
   static_assert(!D0 || MAX_NI == 1, "the dense layer 0 inside the tail launch is built for 16 waves");
   BFrag<MAX_NI> wpre;
@@ -326,8 +344,8 @@ static __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float
     }
   } else {
     if (a.n_layers > 0) {
-      if constexpr (BF) preload_wh(wpre_h, a.L[0].Wbf, a.L[0].h, a.L[0].hp, wave, c16, q);
-      else preload_w(wpre, a.L[0].W, a.L[0].h, a.L[0].hp, wave, c16, q);
+      if constexpr (BF) preload_wh(wpre_h, a.L[0].Wbf, a.L[0].h, a.L[0].hp, wave, c16, q, rot);
+      else preload_w(wpre, a.L[0].W, a.L[0].h, a.L[0].hp, wave, c16, q, rot);
     }
   }
   if constexpr (!D0) {
@@ -413,12 +431,12 @@ static __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float
         if (hp > TAIL_MAX_W) lds_barrier();      // z goes into act1, which held the second half of the features
       }
     } else {
-      if constexpr (BF) gemm16_pre_h<MT>(acc, abf, L.Wbf, h, hp, wave, c16, q, wpre_h);
-      else gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre);
+      if constexpr (BF) gemm16_pre_h<MT>(acc, abf, L.Wbf, h, hp, wave, c16, q, wpre_h, rot);
+      else gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre, rot);
     }
     if (li + 1 < a.n_layers) {
-      if constexpr (BF) preload_wh(wpre_h, a.L[li + 1].Wbf, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q);
-      else preload_w(wpre, a.L[li + 1].W, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q);
+      if constexpr (BF) preload_wh(wpre_h, a.L[li + 1].Wbf, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q, rot);
+      else preload_w(wpre, a.L[li + 1].W, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q, rot);
     }
     STAMP(2 + 4 * (li < 0 ? 0 : li));
     // z = acc + bias into the other activation buffer
@@ -704,6 +722,7 @@ static __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, c16 = lane & 15;
   const int row0 = tile * R;
+  const int rot = a.krot ? (int)(blockIdx.x >> 3) : 0;          // as in the forward body
   STAMP(0);
   // Global inputs of a layer's LayerNorm-backward phase: all loads issued together from clamped
   // addresses, unconditionally (one L2 round trip), and one phase EARLY — for the last layer right here
@@ -748,8 +767,8 @@ static __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float
     BFrag<MAX_NI> wpre;
     BFragH<MAX_NI> wpre_h;
     if (li > 0) {                                                       // for the dA GEMM at the end of this pass
-      if constexpr (BF) preload_wh(wpre_h, L.WTbf, L.hp, h, wave, c16, q);
-      else preload_w<true>(wpre, L.W, L.hp, h, wave, c16, q);
+      if constexpr (BF) preload_wh(wpre_h, L.WTbf, L.hp, h, wave, c16, q, rot);
+      else preload_w<true>(wpre, L.W, L.hp, h, wave, c16, q, rot);
     }
     // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows RPW*w .. of this wave.  Its global inputs
     // (xhat rows, gamma, beta, rstd) were requested one phase early (ln_inputs below).
@@ -861,8 +880,8 @@ static __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float
       for (int i = 0; i < MAX_NI; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ln_inputs(a.L[li - 1]);        // consumed after the GEMM, in the next pass
     lds_barrier();                 // every wave's dZ rows are in `cur`
-    if constexpr (BF) gemm16_pre_h<MT>(acc, abf, L.WTbf, hp, h, wave, c16, q, wpre_h);
-    else gemm16_pre<MT, true>(acc, cur, L.W, hp, h, wave, c16, q, wpre);
+    if constexpr (BF) gemm16_pre_h<MT>(acc, abf, L.WTbf, hp, h, wave, c16, q, wpre_h, rot);
+    else gemm16_pre<MT, true>(acc, cur, L.W, hp, h, wave, c16, q, wpre, rot);
     STAMP(3 + 3 * (a.n_layers - 1 - li));      // dA GEMM of this pass
 #pragma unroll
     for (int i = 0; i < MAX_NI; ++i) {

@@ -48,7 +48,7 @@ class BasisDesc(C.Structure):
                 ("t_bw", C.c_void_p)]
 
 
-ABI_VERSION = 6            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
+ABI_VERSION = 7            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
 MAX_Q = 8
 LOSS_MSE, LOSS_PINBALL = 0, 1
 
@@ -66,7 +66,7 @@ class OptimDesc(C.Structure):
                 ("n", C.c_int64), ("lr", C.c_float), ("lr_dev", C.c_void_p), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step_dev", C.c_void_p),
                 ("max_norm", C.c_float), ("sumsq_parts", C.c_void_p), ("ema_decay", C.c_float),
-                ("shadow", C.POINTER(BF16Shadow))]
+                ("shadow", C.POINTER(BF16Shadow)), ("nonfinite_step", C.c_void_p)]
 
 
 class AdamGroup(C.Structure):
@@ -144,7 +144,7 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p]),
     "stdadk_adamw_ema2_f32": (C.c_int, [C.POINTER(AdamGroup), C.POINTER(AdamGroup), C.c_float, C.c_float,
                                         C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float, C.c_float,
-                                        C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "stdadk_step_uses_window": (C.c_int32, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.c_int32]),
     "stdadk_step_workspace_bytes": (C.c_size_t, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.c_int64,
                                                  C.c_int32]),
@@ -198,7 +198,7 @@ _SIGNATURES = {
                                        C.c_int64, C.c_float, C.c_void_p, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float,
                                        C.c_void_p, C.c_int32, C.c_float, C.c_float, C.POINTER(BF16Shadow),
-                                       C.c_void_p]),
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "stdadk_bf16_shadow_refresh": (C.c_int, [C.c_void_p, C.POINTER(BF16Shadow), C.c_void_p]),
 }
 
@@ -683,20 +683,23 @@ def step_advance(step_dev):
 
 
 def adamw_ema(p, g, m, v, ema, lr, betas, eps, weight_decay, step, max_norm=0.0, sumsq_parts=None,
-              grad_mul=1.0, ema_decay=0.0, lr_dev=None, step_dev=None, shadow=None):
+              grad_mul=1.0, ema_decay=0.0, lr_dev=None, step_dev=None, shadow=None, loss_watch=None,
+              nonfinite_step=None):
+    """`loss_watch` / `nonfinite_step`: the non-finite guard of include/stdadk.h (both or neither)."""
     rc = lib().stdadk_adamw_ema_f32(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"),
                                     _dev(ema, "ema"), p.numel(), lr, _dev(lr_dev, "lr_dev"),
                                     betas[0], betas[1], eps, weight_decay, int(step),
                                     _dev(step_dev, "step_dev"), max_norm, _dev(sumsq_parts, "sumsq"),
                                     0 if sumsq_parts is None else sumsq_parts.numel(),
                                     grad_mul, ema_decay, C.byref(shadow) if shadow is not None else None,
-                                    _stream())
+                                    _dev(loss_watch, "loss_watch"), _dev(nonfinite_step, "nonfinite_step"), _stream())
     _check(rc, "stdadk_adamw_ema_f32")
 
 
 def make_optim(p, g, m, v, ema, lr, lr_dev, betas, eps, weight_decay, step_dev, max_norm, sumsq_parts, ema_decay,
-               shadow=None):
+               shadow=None, nonfinite_step=None):
     o = OptimDesc()
+    o.nonfinite_step = _dev(nonfinite_step, "nonfinite_step")
     o._keep = shadow                 # the descriptor points at it
     o.shadow = C.pointer(shadow) if shadow is not None else None
     o.p, o.g, o.m, o.v, o.ema = _dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), _dev(ema, "ema")
@@ -749,10 +752,12 @@ def make_adam_group(p, g, m, v, ema, lr, lr_dev=None, max_norm=0.0, sumsq_parts=
     return gr
 
 
-def adamw_ema2(group0, group1, betas, eps, weight_decay, step, grad_mul=1.0, ema_decay=0.0, step_dev=None):
+def adamw_ema2(group0, group1, betas, eps, weight_decay, step, grad_mul=1.0, ema_decay=0.0, step_dev=None,
+               loss_watch=None, nonfinite_step=None):
     """stdadk_adamw_ema_f32 on two parameter groups (make_adam_group) in one launch."""
     rc = lib().stdadk_adamw_ema2_f32(C.byref(group0), C.byref(group1), betas[0], betas[1], eps, weight_decay,
-                                     int(step), _dev(step_dev, "step_dev"), grad_mul, ema_decay, _stream())
+                                     int(step), _dev(step_dev, "step_dev"), grad_mul, ema_decay,
+                                     _dev(loss_watch, "loss_watch"), _dev(nonfinite_step, "nonfinite_step"), _stream())
     _check(rc, "stdadk_adamw_ema2_f32")
 
 

@@ -88,6 +88,41 @@ def allreduce_gradients(flat_grad, group=None):
     return flat_grad
 
 
+_RS_NATIVE = {}        # backend name -> does reduce_scatter_tensor work (gloo: not for every build / device)
+
+
+def reduce_scatter_gradients(flat_grad, out_slice, group=None):
+    """SUM reduce-scatter of the flat gradient (length world * chunk): `out_slice` = this rank's chunk
+    flat_grad[rank * chunk:(rank + 1) * chunk] (a view: in place, as RCCL allows) receives the sum over ranks of
+    that chunk.  On the xGMI full mesh each GPU exchanges 1/world of the buffer with every peer directly -- all 7
+    links at once -- where a ring all-reduce passes 2 (world-1)/world of it over one link.
+    Backends without the collective (gloo in the CPU / one-GPU rehearsals) fall back to all-reduce: the slice then
+    holds the same sums."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return out_slice
+    backend = dist.get_backend(group)
+    if _RS_NATIVE.get(backend, True):
+        try:
+            dist.reduce_scatter_tensor(out_slice, flat_grad, op=dist.ReduceOp.SUM, group=group)
+            _RS_NATIVE[backend] = True
+            return out_slice
+        except (RuntimeError, NotImplementedError) as e:
+            if backend == "nccl":
+                raise                      # RCCL has it: a failure there is an error, not a missing feature
+            _RS_NATIVE[backend] = False    # every rank runs the same build: all take this branch together
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return out_slice
+
+
+def allgather_parameters(flat, my_slice, group=None):
+    """All-gather of the ranks' stepped parameter chunks into the flat buffer (`my_slice` may be this rank's own
+    chunk of `flat`: in place)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return flat
+    dist.all_gather_into_tensor(flat, my_slice, group=group)
+    return flat
+
+
 def clip_coefficient(flat_grad, max_norm):
     """min(1, max_norm/(||g||+1e-6)) of the REDUCED gradient (torch.nn.utils.clip_grad_norm_)."""
     if not max_norm or max_norm <= 0:

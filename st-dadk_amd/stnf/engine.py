@@ -13,6 +13,7 @@ runs the same arithmetic as one chain of HIP kernels on one stream with
     (SURVEY.md §7 "DDP equivalence"), with the clip norm taken after the reduction.
 """
 import math
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -28,12 +29,13 @@ from . import distributed as D
 _INDEXED_MIN_B = 8192
 
 
-def flatten_parameters(model, transpose_first=True):
+def flatten_parameters(model, transpose_first=True, pad_multiple=4):
     """Move every trainable parameter of `model` into one flat fp32 buffer (the parameters become
     views, so state_dict()/checkpoints keep their names and shapes).  Each parameter is padded to a
     multiple of 4 floats so every view is 16-byte aligned.  With `transpose_first` the first
     Linear's weight is STORED (in,out) row-major — the layout the window kernels gather rows from —
     and `model.mlp[0].weight` becomes its .t() view (same values, shape (out,in)).
+    The buffer's length is rounded up to `pad_multiple` floats (zeros: equal shards of a sharded optimiser).
     Returns (flat, [(name, offset, numel)])."""
     params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     dev = params[0][1].device
@@ -41,6 +43,7 @@ def flatten_parameters(model, transpose_first=True):
     for n, p in params:
         offs.append((n, total, p.numel()))
         total += (p.numel() + 3) // 4 * 4
+    total = (total + pad_multiple - 1) // pad_multiple * pad_multiple
     flat = torch.zeros(total, device=dev, dtype=torch.float32)
     first_w = model._body[0].weight
     for (n, p), (_, o, k) in zip(params, offs):
@@ -128,7 +131,23 @@ class TrainStep:
     config keys of scripts/train_st_interp.py:674-691): value into the loss accumulator, gradient into dW0.
 
     Launch mode: an eager chain of kernels by default (`use_graph=True` replays it from a hipGraph);
-    `step_indexed(..., next_idx=...)` / `run_epoch` overlap the next batch's preparation with the step."""
+    `step_indexed(..., next_idx=...)` / `run_epoch` overlap the next batch's preparation with the step.
+
+    Data parallel (one process per GPU, observations sharded, `torch.distributed` initialised): the replicas are
+    made identical at construction (`sync_init`: rank 0's parameters, buffers and dropout base seed are broadcast --
+    data-dependent knot initialisers see different shards on every rank), then per step either
+      * `shard_optimizer=False`: ONE all-reduce of the flat gradient, clip norm + AdamW + EMA replicated; or
+      * `shard_optimizer=True`: reduce-scatter of the flat gradient (every rank receives the SUM of its 1/world
+        slice -- on the xGMI full mesh all 7 links of a GPU carry 1/8 of the buffer at once instead of a ring passing
+        7/8 of it over one link), sum of squares of the local slice, one all-reduce of the 2 x 256 clip-norm
+        partials, AdamW + EMA on the slice only (Adam moments and the EMA shadow exist only for it: 1/world of the
+        optimiser's HBM traffic and memory), all-gather of the stepped parameters.  Same arithmetic as the
+        replicated mode (scripts/train_st_interp.py:696-712: global-norm clip, step, EMA) up to the order of the
+        clip norm's partial sums.
+
+    Non-finite guard (`nonfinite_guard`): the optimiser launch of every step checks the objective accumulator on the
+    device; `first_nonfinite_step()` / `run_epoch(check_every=k)` report or stop at the first batch whose objective
+    was NaN/inf, as scripts/train_st_interp.py:724-733 does, without a host sync per step."""
 
     def __init__(self, model, lr=2e-2, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
                  grad_clip=10.0, ema_decay=None, max_batch=4096, use_graph=False,
@@ -137,7 +156,8 @@ class TrainStep:
                  non_crossing_lambda=0.0, basis_lr_ratio=0.05, basis_clip_ratio=0.1,
                  domain_penalty_weight=0.0, movement_penalty_weight=0.0, sparsity_penalty_type="none",
                  sparsity_lambda_l1=0.001, sparsity_lambda_group=0.01, sparsity_apply_to_spatial=True,
-                 sparsity_apply_to_temporal=True, seed=None, world_size=None, dtype="f32"):
+                 sparsity_apply_to_temporal=True, seed=None, world_size=None, dtype="f32", shard_optimizer=False,
+                 sync_init=True, nonfinite_guard=True):
         self.model = model
         if dtype not in ("f32", "bf16"):
             raise ValueError(f"unknown dtype '{dtype}'; use 'f32' or 'bf16'")
@@ -157,11 +177,38 @@ class TrainStep:
         self.dev = next(model.parameters()).device
         if self.dev.type != "cuda":
             raise RuntimeError("TrainStep needs the model on a HIP device; there is no CPU path")
-        self.flat, self.offsets = flatten_parameters(model, transpose_first=True)
+        # distributed
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.distributed = bool(distributed)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.rank = dist.get_rank(process_group) if self.distributed else 0
+        if world_size is not None:
+            # tests: this engine plays one of `world_size` ranks whose gradients the caller sums itself
+            # (split path, 1/world shares of the parameter-level penalties); see set_virtual_rank
+            self.world = int(world_size)
+        self.shard = bool(shard_optimizer) and self.world > 1
+        if self.distributed and sync_init:
+            # identical replicas: parameters AND buffers (knot tables of the gmm / random_site initialisers depend on
+            # the rank's own train_coords) from rank 0, before anything is derived from them
+            with torch.no_grad():
+                for tns in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(tns.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                   group=process_group)
+        # every rank's slice of the flat buffers starts on a 128-byte line: chunk = a multiple of 32 floats
+        self.flat, self.offsets = flatten_parameters(model, transpose_first=True,
+                                                     pad_multiple=32 * self.world if self.shard else 4)
         self.grad = torch.zeros_like(self.flat)
-        self.m = torch.zeros_like(self.flat)
-        self.v = torch.zeros_like(self.flat)
-        self.ema = self.flat.clone() if ema_decay is not None else None
+        self.chunk = self.flat.numel() // self.world if self.shard else self.flat.numel()
+        self.lo = self.rank * self.chunk if self.shard else 0
+        self.hi = self.lo + self.chunk
+        # sharded optimiser: Adam moments and the EMA shadow exist for this rank's slice [lo, hi) only
+        self.m = torch.zeros(self.chunk, device=self.dev)
+        self.v = torch.zeros(self.chunk, device=self.dev)
+        self.ema = self.flat[self.lo:self.hi].clone() if ema_decay is not None else None
+        self._ema_backup = None
+        self._vstate = {}          # tests (set_virtual_rank with the sharded optimiser): rank -> (m, v, ema) slices
         self.ema_decay = 0.0 if ema_decay is None else float(ema_decay)
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.grad_clip = float(grad_clip or 0.0)
@@ -249,17 +296,11 @@ class TrainStep:
         # edges cost more than the overlap of ~20 us kernels buys), hence off by default.
         self.aux_stream = torch.cuda.Stream(device=self.dev) if two_streams else None
         self.rows_seen = 0
-        # distributed
-        if distributed is None:
-            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
-        self.distributed = bool(distributed)
-        self.pg = process_group
-        self.world = dist.get_world_size(process_group) if self.distributed else 1
-        self.rank = dist.get_rank(process_group) if self.distributed else 0
-        if world_size is not None:
-            # tests: this engine plays one of `world_size` ranks whose gradients the caller sums itself
-            # (split path, 1/world shares of the parameter-level penalties); see set_virtual_rank
-            self.world = int(world_size)
+        if self.distributed and sync_init:
+            bs = torch.tensor([self.base_seed], dtype=torch.int64, device=self.dev)
+            dist.broadcast(bs, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                           group=process_group)
+            self.base_seed = int(bs.item())
         self.seed = _rank_seed(self.base_seed, self.rank)
         # graph
         self.use_graph = bool(use_graph)
@@ -277,9 +318,18 @@ class TrainStep:
         self._sumsq512 = torch.zeros(N.GRADSQ_PARTS, device=self.dev)
         self._pipe = None          # two workspaces + side stream of the pipelined batch preparation
         self._prepared = None      # ((idx data_ptr, numel), workspace index, idx tensor) of the announced batch
-        self.time_allreduce = False   # bench: bracket the gradient all-reduce with timing events
+        self.time_allreduce = False   # bench: bracket the step's collectives with timing events
         self.allreduce_events = []
-        self._sched = None         # run_epoch under data parallelism: (dataset key, per-step per-rank batch sizes)
+        # clip-norm partials of both parameter groups in ONE buffer (the sharded optimiser all-reduces it once)
+        self._sumsq_all = torch.zeros(2 * N.SUMSQ_PARTS, device=self.dev)
+        if self.shard:
+            self.sumsq = self._sumsq_all[:N.SUMSQ_PARTS]
+            if self.learnable:
+                self.sumsq_basis = self._sumsq_all[N.SUMSQ_PARTS:]
+        self._rs_native = None     # does the backend have reduce_scatter_tensor (gloo: emulated by all-reduce + slice)
+        # non-finite guard: first (1-based) step whose objective left the accumulator NaN/inf, 0 = none so far
+        self.nonfinite = torch.zeros(1, device=self.dev, dtype=torch.int32) if nonfinite_guard else None
+        self.stopped_at = None     # run_epoch(check_every=...): index of the batch it stopped after, or None
 
     # ------------------------------------------------------------------------------------
     def _install_bf16_copies(self):
@@ -300,6 +350,7 @@ class TrainStep:
             regions.append((by_name[names[id(w)]][0], h, hp, wb, wt))
         self._shadow_regions = regions
         m._bf16_engine = pairs
+        m._bf16_refresh = weakref.WeakMethod(self.refresh_bf16)
         self.refresh_bf16()
 
     def _shadow(self, base=0):
@@ -319,6 +370,13 @@ class TrainStep:
         sh = self._shadow(0)
         if sh is not None:
             N.bf16_shadow_refresh(self.flat, sh)
+            self.model._bf16_key = self.model._bf16_master_key()
+
+    def _check_bf16_current(self):
+        """The operand copies follow this engine's own optimiser; anything else that rewrote the master weights
+        (load_state_dict, ModelEMA.apply_shadow / restore, an in-place edit under no_grad) moves the key."""
+        if self._shadow_regions and self.model._bf16_key != self.model._bf16_master_key():
+            self.refresh_bf16()
 
     def set_lr(self, lr):
         self.lr = float(lr)
@@ -347,23 +405,97 @@ class TrainStep:
                 self._optim = N.make_optim(self.flat, self.grad, self.m, self.v, self.ema, self.lr, self.lr_dev,
                                            self.betas, self.eps, self.wd, self.step_dev, self.grad_clip,
                                            self._sumsq512 if self.grad_clip > 0 else None, self.ema_decay,
-                                           shadow=self._shadow(0))
+                                           shadow=self._shadow(0), nonfinite_step=self.nonfinite)
             N.train_step(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y,
                          idx if not prebinned else None, B, D.grad_scale(global_rows, Q), self.loss_sum, ws, flags,
                          self._optim, seed=self.seed, loss_desc=self._loss_desc(y.shape[1]),
                          sparsity_desc=self._sparsity)
             return
         self._enqueue_grads(X, coords, t, y, B, global_rows, idx=idx, ws=ws, prebinned=prebinned)
+        if self.shard:
+            self._enqueue_sharded_optimizer()
+            return
         if self.distributed:
-            if self.time_allreduce:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                D.allreduce_gradients(self.grad, self.pg)
-                e1.record()
-                self.allreduce_events.append((e0, e1))
-            else:
-                D.allreduce_gradients(self.grad, self.pg)
+            self._timed(lambda: D.allreduce_gradients(self.grad, self.pg))
         self._enqueue_optimizer()
+
+    def _timed(self, fn):
+        """Run a collective; under `time_allreduce` bracket it with timing events on the step's stream."""
+        if not self.time_allreduce:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.allreduce_events.append((e0, e1))
+        return out
+
+    # ---- sharded optimiser (shard_optimizer=True) ---------------------------------------------------------
+    def _local(self, a, b):
+        """This rank's part of the flat range [a, b): (start, stop) in flat coordinates, stop <= start if empty."""
+        return max(a, self.lo), min(b, self.hi)
+
+    def _shard_sumsq(self):
+        """Sum of squares of the REDUCED gradient on this rank's slice, per parameter group, into the 2 x 256
+        partials of `_sumsq_all` (a group this rank holds nothing of contributes zeros); advances the device step
+        counter once.  The SUM of the ranks' partial vectors gives the global clip norms."""
+        ke = self.knot_end
+        a0, b0 = self._local(ke, self.flat.numel())
+        g_mlp = self.grad[a0:max(b0, a0)]
+        if self.grad_clip <= 0:
+            N.step_advance(self.step_dev)
+            return
+        if ke:
+            a1, b1 = self._local(0, ke)
+            N.sumsq2(g_mlp, self.sumsq, self.grad[a1:max(b1, a1)], self.sumsq_basis, step_inc=self.step_dev)
+        else:
+            N.sumsq(g_mlp, self.sumsq, step_inc=self.step_dev)
+
+    def _shard_adamw(self):
+        """AdamW + EMA on this rank's slice (moments / EMA shadow indexed from `lo`), each group with its own learning
+        rate and its GLOBAL clip norm (the summed partials in `_sumsq_all`)."""
+        ke, lo = self.knot_end, self.lo
+        clip = self.grad_clip > 0
+        ema = self.ema
+
+        def group(a, b, lr, lr_dev, max_norm, parts):
+            return N.make_adam_group(self.flat[a:b], self.grad[a:b], self.m[a - lo:b - lo], self.v[a - lo:b - lo],
+                                     ema[a - lo:b - lo] if ema is not None else None, lr, lr_dev,
+                                     max_norm if clip else 0.0, parts if clip else None)
+        a0, b0 = self._local(ke, self.flat.numel())
+        a1, b1 = self._local(0, ke)
+        groups = []
+        if b0 > a0:
+            groups.append(group(a0, b0, self.lr, self.lr_dev, self.grad_clip, self.sumsq))
+        if ke and b1 > a1:
+            groups.append(group(a1, b1, self.basis_lr, self.basis_lr_dev, self.basis_clip, self.sumsq_basis))
+        watch = self.loss_sum if self.nonfinite is not None else None
+        if len(groups) == 2:
+            N.adamw_ema2(groups[0], groups[1], self.betas, self.eps, self.wd, self.step_count + 1,
+                         ema_decay=self.ema_decay, step_dev=self.step_dev, loss_watch=watch,
+                         nonfinite_step=self.nonfinite)
+        elif groups:
+            g = groups[0]
+            a, b = (a0, b0) if b0 > a0 else (a1, b1)
+            N.adamw_ema(self.flat[a:b], self.grad[a:b], self.m[a - lo:b - lo], self.v[a - lo:b - lo],
+                        ema[a - lo:b - lo] if ema is not None else None, g.lr, self.betas, self.eps, self.wd,
+                        self.step_count + 1, max_norm=g.max_norm, sumsq_parts=self.sumsq if b0 > a0 else self.sumsq_basis,
+                        ema_decay=self.ema_decay, lr_dev=self.lr_dev if b0 > a0 else self.basis_lr_dev,
+                        step_dev=self.step_dev, loss_watch=watch, nonfinite_step=self.nonfinite)
+
+    def _enqueue_sharded_optimizer(self):
+        """reduce-scatter(gradient) -> local sum of squares -> all-reduce(2 x 256 partials) -> AdamW/EMA on the slice
+        -> all-gather(parameters) [-> bf16 operand copies re-rounded from the gathered master weights]."""
+        mine = self.grad[self.lo:self.hi]
+        self._timed(lambda: D.reduce_scatter_gradients(self.grad, mine, self.pg))
+        self._shard_sumsq()
+        if self.grad_clip > 0:
+            n = 2 * N.SUMSQ_PARTS if self.knot_end else N.SUMSQ_PARTS
+            self._timed(lambda: D.allreduce_gradients(self._sumsq_all[:n], self.pg))
+        self._shard_adamw()
+        self._timed(lambda: D.allgather_parameters(self.flat, self.flat[self.lo:self.hi], self.pg))
+        if self._shadow_regions:
+            self.refresh_bf16()
 
     def _enqueue_grads(self, X, coords, t, y, B, global_rows, idx=None, ws=None, prebinned=False):
         """Split path, first half: this rank's share of the global-batch gradient into `self.grad` (every
@@ -416,6 +548,7 @@ class TrainStep:
         """Split path, second half: clip norm(s) of the (reduced) gradient, AdamW + EMA; advances the device
         step counter once."""
         ke = self.knot_end
+        watch = self.loss_sum if self.nonfinite is not None else None
         if ke and self.grad_clip > 0:
             # learnable knots: both groups' clip norms in one launch, both AdamW/EMA updates in one launch
             N.sumsq2(self.grad[ke:], self.sumsq, self.grad[:ke], self.sumsq_basis, step_inc=self.step_dev)
@@ -427,7 +560,8 @@ class TrainStep:
                                        ema[:ke] if ema is not None else None, self.basis_lr, self.basis_lr_dev,
                                        self.basis_clip, self.sumsq_basis)
             N.adamw_ema2(g_mlp, g_knot, self.betas, self.eps, self.wd, self.step_count + 1,
-                         ema_decay=self.ema_decay, step_dev=self.step_dev)
+                         ema_decay=self.ema_decay, step_dev=self.step_dev, loss_watch=watch,
+                         nonfinite_step=self.nonfinite)
             return
         if self.grad_clip > 0:
             N.sumsq(self.grad[ke:], self.sumsq, step_inc=self.step_dev)
@@ -439,7 +573,7 @@ class TrainStep:
         N.adamw_ema(self.flat[ke:], self.grad[ke:], self.m[ke:], self.v[ke:], ema[ke:] if ema is not None else None,
                     self.lr, self.betas, self.eps, self.wd, self.step_count + 1, max_norm=self.grad_clip,
                     sumsq_parts=self.sumsq, ema_decay=self.ema_decay, lr_dev=self.lr_dev, step_dev=self.step_dev,
-                    shadow=self._shadow(ke))
+                    shadow=self._shadow(ke), loss_watch=watch, nonfinite_step=self.nonfinite)
         if ke:
             N.adamw_ema(self.flat[:ke], self.grad[:ke], self.m[:ke], self.v[:ke], ema[:ke] if ema is not None else None,
                         self.basis_lr, self.betas, self.eps, self.wd, self.step_count + 1, max_norm=self.basis_clip,
@@ -449,6 +583,15 @@ class TrainStep:
     def set_virtual_rank(self, rank):
         """Tests of the data-parallel arithmetic on one GPU: play rank `rank` of `world_size` (dropout stream
         of that rank; the caller sums the ranks' `grad` buffers between _enqueue_grads and _enqueue_optimizer)."""
+        if self.shard:
+            # the sharded optimiser state of every virtual rank is kept: playing rank r swaps its (m, v, ema) in
+            self._vstate[self.rank] = (self.m, self.v, self.ema)
+            lo = int(rank) * self.chunk
+            if int(rank) not in self._vstate:
+                self._vstate[int(rank)] = (torch.zeros_like(self.m), torch.zeros_like(self.v),
+                                           self.flat[lo:lo + self.chunk].clone() if self.ema is not None else None)
+            self.m, self.v, self.ema = self._vstate[int(rank)]
+            self.lo, self.hi = lo, lo + self.chunk
         self.rank = int(rank)
         self.seed = _rank_seed(self.base_seed, self.rank)
 
@@ -470,6 +613,7 @@ class TrainStep:
         B = coords.shape[0]
         if B > self.max_batch:
             raise RuntimeError(f"batch {B} > max_batch {self.max_batch}")
+        self._check_bf16_current()
         if global_rows is None:
             global_rows = B * self.world
         coords = coords.contiguous().float()
@@ -491,6 +635,8 @@ class TrainStep:
         # the kernels update the parameters through raw pointers (no autograd version bump): Predictors that
         # cache derived tensors (the delta head's output layer) watch this counter
         self.model._engine_version = getattr(self.model, "_engine_version", 0) + 1
+        if self._shadow_regions:
+            self.model._bf16_key = self.model._bf16_master_key()      # the optimiser kernel has just re-rounded them
 
     def step_indexed(self, coords_all, t_all, y_all, idx, X_all=None, global_rows=None, next_idx=None):
         """One optimisation step on rows `idx` (int64 device tensor) of device-RESIDENT observation
@@ -508,6 +654,7 @@ class TrainStep:
         B = idx.numel()
         if B > self.max_batch:
             raise RuntimeError(f"batch {B} > max_batch {self.max_batch}")
+        self._check_bf16_current()
         if global_rows is None:
             global_rows = B * self.world
         p, yc = self.model.p, y_all.shape[1]
@@ -525,7 +672,9 @@ class TrainStep:
         # a captured graph reads the indices from a static buffer; the eager chain takes them as they are
         src = ib if graphed else (idx if idx.is_contiguous() else idx.contiguous())
         if self.uses_window and not graphed and (next_idx is not None or self._prepared is not None):
-            self._step_pipelined(coords_all, t_all, y_all, Xa, src, next_idx, B, global_rows)
+            # announcements are keyed on the CALLER's tensors (a .contiguous() copy has a new address every call)
+            self._step_pipelined(coords_all, t_all, y_all, Xa, src, next_idx, B, global_rows,
+                                 key=(idx.data_ptr(), idx.numel(), idx.stride(0) if idx.dim() else 1))
             self._stepped(B)
             return
 
@@ -556,33 +705,47 @@ class TrainStep:
             enqueue()
         self._stepped(B)
 
-    def run_epoch(self, dataset, batch_size, generator=None, shuffle=True):
+    def run_epoch(self, dataset, batch_size, generator=None, shuffle=True, check_every=0):
         """One pass over a `stnf.dataio.device_dataset.DeviceDataset` in shuffled mini-batches (the
         epoch loop of scripts/train_st_interp.py:608-724 with the set resident in HBM): every step
         announces the next batch so that its preparation overlaps the running step.  Returns the mean
         batch objective of the epoch (ONE host sync).
 
-        Data-parallel: `dataset` is this rank's shard.  The shard sizes are all-gathered once per data set and
-        `stnf.distributed.epoch_schedule` gives every rank the same number of steps, a non-empty batch in each
-        and each step's global row count -- no per-step collective besides the gradient all-reduce."""
+        Non-finite objectives: the reference leaves the epoch at the first batch whose loss is NaN
+        (scripts/train_st_interp.py:724-733, after that batch's optimiser step).  The device-side guard records that
+        step without a host sync; `check_every=k` reads it every k steps (one 4-byte read = one sync each) and stops
+        the epoch there (`stopped_at` = index of the last batch stepped), `check_every=0` runs the epoch through and
+        leaves the step in `first_nonfinite_step()`.
+
+        Data-parallel: `dataset` is this rank's shard.  The shard sizes are all-gathered once per call (8 bytes per
+        rank: every rank enters it, whatever it has cached) and `stnf.distributed.epoch_schedule` gives every rank the
+        same number of steps, a non-empty batch in each and each step's global row count -- no per-step collective
+        besides the gradient exchange.  A `check_every` poll is a MAX all-reduce of the guard word, so that every rank
+        leaves the epoch after the same step."""
         if self.distributed:
-            key = (id(dataset), len(dataset), int(batch_size))
-            if self._sched is None or self._sched[0] != key:
-                sizes = D.gather_shard_sizes(len(dataset), self.pg, device=self.dev)
-                self._sched = (key, D.epoch_schedule(sizes, int(batch_size)))
-            table = self._sched[1]
+            sizes = D.gather_shard_sizes(len(dataset), self.pg, device=self.dev)
+            table = D.epoch_schedule(sizes, int(batch_size))
             batches = dataset.epoch_batches([row[self.rank] for row in table], generator=generator, shuffle=shuffle)
             rows = [sum(row) for row in table]
         else:
             batches = dataset.epoch_batches(batch_size, generator=generator, shuffle=shuffle)
             rows = [None] * len(batches)
+        self.stopped_at = None
         for i, idx in enumerate(batches):
             nxt = batches[i + 1] if i + 1 < len(batches) else None
             self.step_indexed(dataset.coords, dataset.t, dataset.y, idx, X_all=dataset.X, global_rows=rows[i],
                               next_idx=nxt)
+            if check_every and self.nonfinite is not None and (i + 1) % check_every == 0 and nxt is not None:
+                bad = self.nonfinite
+                if self.distributed:
+                    bad = bad.clone()
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.pg)
+                if int(bad.item()) > 0:
+                    self.stopped_at = i
+                    break
         return self.mean_loss()
 
-    def _step_pipelined(self, coords_all, t_all, y_all, Xa, idx, next_idx, B, global_rows):
+    def _step_pipelined(self, coords_all, t_all, y_all, Xa, idx, next_idx, B, global_rows, key=None):
         """Step on a batch that was (or is now) binned into one of two workspaces, and batch
         preparation of `next_idx` on the side stream into the other one."""
         main = torch.cuda.current_stream(self.dev)
@@ -596,11 +759,16 @@ class TrainStep:
         st = self.state
         prep = self._prepared
         self._prepared = None
-        if prep is not None and prep[0] == (idx.data_ptr(), idx.numel()):
+        if key is None:
+            key = (idx.data_ptr(), idx.numel(), idx.stride(0) if idx.dim() else 1)
+        if prep is not None and prep[0] == key:
             wsi, prebinned = prep[1], True
             _wait(main, pp["binned"])
         else:
             wsi, prebinned = 1 - pp["last"], False        # not announced: bin inside the step, in place
+            if prep is not None:
+                # another batch was announced: the side stream may still be binning it into exactly this workspace
+                _wait(main, pp["binned"])
         if next_idx is not None:
             nxt = next_idx if next_idx.is_contiguous() else next_idx.contiguous()
             # the side stream starts after everything enqueued on the main stream so far: the step that last
@@ -620,7 +788,8 @@ class TrainStep:
             with torch.cuda.stream(pp["stream"]):
                 N.bin_batch(st.basis, st.desc, coords_all, t_all, Xa, y_all, nxt, pp["ws"][wsj], st.flags)
                 pp["binned"].record(pp["stream"])
-            self._prepared = ((nxt.data_ptr(), nxt.numel()), wsj, nxt)
+            self._prepared = ((next_idx.data_ptr(), next_idx.numel(), next_idx.stride(0) if next_idx.dim() else 1),
+                              wsj, nxt)
         pp["last"] = wsi
 
     def _step_graph(self, X, coords, t, y, B, global_rows):
@@ -660,14 +829,37 @@ class TrainStep:
 
     def swap_in_ema(self):
         """Exchange the live parameters with the EMA shadow (validation under EMA weights,
-        scripts/train_st_interp.py:739,790); call again to swap back."""
+        scripts/train_st_interp.py:739,790); call again to swap back.  With the sharded optimiser the shadow exists in
+        slices: the first call all-gathers it into the parameter buffer (the live values are kept aside), the
+        second puts the live values back -- a collective, every rank must call it."""
         if self.ema is None:
             raise RuntimeError("EMA is disabled")
-        tmp = self.flat.clone()
-        self.flat.copy_(self.ema)
-        self.ema.copy_(tmp)
-        self.refresh_bf16()
+        if self.shard:
+            if self._ema_backup is None:
+                self._ema_backup = self.flat.clone()
+                if self.distributed:
+                    D.allgather_parameters(self.flat, self.ema, self.pg)
+                else:                               # virtual ranks (tests): the slices this engine has played
+                    self._vstate[self.rank] = (self.m, self.v, self.ema)
+                    for r, (_, _, e) in self._vstate.items():
+                        self.flat[r * self.chunk:(r + 1) * self.chunk].copy_(e)
+            else:
+                self.flat.copy_(self._ema_backup)
+                self._ema_backup = None
+        else:
+            tmp = self.flat.clone()
+            self.flat.copy_(self.ema)
+            self.ema.copy_(tmp)
         self.model._engine_version = getattr(self.model, "_engine_version", 0) + 1
+        self.refresh_bf16()
+
+    def first_nonfinite_step(self):
+        """1-based number of the first optimisation step whose batch objective was NaN/inf, or None (ONE host sync;
+        scripts/train_st_interp.py:724-733 prints and leaves the epoch there)."""
+        if self.nonfinite is None:
+            raise RuntimeError("the engine was built with nonfinite_guard=False")
+        v = int(self.nonfinite.item())
+        return v if v > 0 else None
 
 
 class Predictor:

@@ -393,7 +393,9 @@ class STInterpMLP(nn.Module):
         # "f32" (the reference's arithmetic) or "bf16" (BASELINE config C3: the Linear layers after the first take
         # bf16 operands on the matrix cores, fp32 accumulation / LayerNorm / loss / master weights)
         self.compute_dtype = "f32"
-        self._bf16_engine = None
+        self._bf16_engine = None       # persistent bf16 operand copies installed by an engine (TrainStep(dtype="bf16"))
+        self._bf16_refresh = None      # weak reference to that engine's refresh_bf16
+        self._bf16_key = None          # identity + versions of the master weights the copies were rounded from
         # diagnostics: True forces the materialising (dense) kernels even where the window path applies
         self.force_dense_path = False
         # diagnostics: True takes the window kernels wherever supported, also for small knot tables
@@ -430,7 +432,12 @@ class STInterpMLP(nn.Module):
         layer order) by stdadk_bf16_shadow_refresh.  An engine (stnf.engine.TrainStep) installs persistent
         copies that its optimiser kernel keeps current; otherwise they are made afresh for the call."""
         if self._bf16_engine is not None:
-            return self._bf16_engine
+            refresh = self._bf16_refresh() if self._bf16_refresh is not None else None
+            if refresh is not None:
+                if self._bf16_key != self._bf16_master_key():
+                    refresh()              # load_state_dict / ModelEMA swap / in-place edit since the last rounding
+                return self._bf16_engine
+            self._bf16_engine = None       # the engine is gone: nothing keeps its copies current any more
         out = [None] * len(weights)
         n_hidden = len(self.hidden_dims)
         for l in range(1, n_hidden):
@@ -441,6 +448,14 @@ class STInterpMLP(nn.Module):
             N.bf16_shadow_refresh(w, N.make_bf16_shadow([(0, h, hp, pair[0], pair[1])]))
             out[l] = pair
         return out
+
+    def _bf16_master_key(self):
+        """What the bf16 operand copies depend on: storage and autograd version of every hidden Linear weight after
+        the first (optimizer.step(), load_state_dict and ModelEMA's copies under no_grad all bump the version) and
+        the engine's own step counter (its kernels write through raw pointers and re-round in the same pass)."""
+        lins = self._linears()
+        return (getattr(self, "_engine_version", 0),) + tuple(
+            (lins[l].weight.data_ptr(), lins[l].weight._version) for l in range(1, len(self.hidden_dims)))
 
     def _pack(self, flat_list, bf16=None):
         """Tensors in _body_params() order (+ the derived [Wo, bo] under the delta head) -> ABI struct."""

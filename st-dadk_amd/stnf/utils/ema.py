@@ -35,15 +35,22 @@ class ModelEMA:
             for n, p in self.model.named_parameters():
                 if p.requires_grad:
                     self.backup[n] = p.data.clone()
-                    p.data.copy_(self.shadow[n])
+                    p.copy_(self.shadow[n])          # on the parameter, not .data: the autograd version moves
+        self._touched()
 
     def restore(self):
         """Put the training weights back (reference ema.py:79-89), again in place."""
         with torch.no_grad():
             for n, p in self.model.named_parameters():
                 if p.requires_grad:
-                    p.data.copy_(self.backup[n])
+                    p.copy_(self.backup[n])
         self.backup = {}
+        self._touched()
+
+    def _touched(self):
+        """Everything derived from the weights (a Predictor's cached output layer / transposed W0, an engine's bf16
+        operand copies) keys on the parameters' versions and on this counter: both move with every swap."""
+        self.model._engine_version = getattr(self.model, "_engine_version", 0) + 1
 
     def state_dict(self):
         return {'decay': self.decay, 'shadow': self.shadow}

@@ -191,3 +191,96 @@ def test_epoch_schedule_keeps_collectives_matched_gloo(sizes, B):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert res[0][1] == res[1][1] and abs(res[0][2] - res[1][2]) < 1e-12
+
+
+# ------------------------------------------------------------------ sharded optimiser: the collective pattern
+def _shard_worker(rank, world, port, P, ke, q):
+    """The host-side pattern of TrainStep(shard_optimizer=True) in float64 torch on the CPU: reduce-scatter of the
+    flat gradient, per-slice / per-group sums of squares, ONE all-reduce of the partial vector, clipped AdamW + EMA on
+    the slice, all-gather of the parameters -- against the replicated pattern (all-reduce, everything everywhere)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "st-dadk_amd"))
+    from stnf import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        chunk = -(-P // (32 * world)) * 32                 # the engine's padding: slices start on 128-byte lines
+        n = chunk * world
+        lo, hi = rank * chunk, (rank + 1) * chunk
+        g0 = torch.Generator().manual_seed(5)
+        p_all = torch.zeros(n, dtype=torch.float64)
+        p_all[:P] = torch.randn(P, generator=g0, dtype=torch.float64)
+        gr = torch.Generator().manual_seed(100 + rank)      # every rank's own share of the gradient
+        g_loc = torch.zeros(n, dtype=torch.float64)
+        g_loc[:P] = torch.randn(P, generator=gr, dtype=torch.float64)
+        lr, lr_k, clip, clip_k, b1, b2, eps, wd, dec = 2e-2, 1e-3, 0.7, 0.07, 0.9, 0.999, 1e-8, 5e-4, 0.9
+
+        def adam(p, g, m, v, e, coef, lr_):
+            g = g * coef
+            p = p * (1 - lr_ * wd)
+            m = b1 * m + (1 - b1) * g
+            v = b2 * v + (1 - b2) * g * g
+            p = p - lr_ / (1 - b1) * m / (v.sqrt() / (1 - b2) ** 0.5 + eps)
+            return p, m, v, dec * e + (1 - dec) * p
+
+        # replicated reference
+        g_full = g_loc.clone()
+        D.allreduce_gradients(g_full)
+        ck = min(1.0, clip_k / (float(g_full[:ke].norm()) + 1e-6)) if ke else 1.0
+        cm = min(1.0, clip / (float(g_full[ke:].norm()) + 1e-6))
+        ref = p_all.clone()
+        ref_e = p_all.clone()
+        z = torch.zeros(n, dtype=torch.float64)
+        ref[:ke], _, _, ref_e[:ke] = adam(p_all[:ke], g_full[:ke], z[:ke], z[:ke], p_all[:ke], ck, lr_k)
+        ref[ke:], _, _, ref_e[ke:] = adam(p_all[ke:], g_full[ke:], z[ke:], z[ke:], p_all[ke:], cm, lr)
+        # sharded
+        g_sh = g_loc.clone()
+        mine = g_sh[lo:hi]
+        D.reduce_scatter_gradients(g_sh, mine)
+        assert torch.allclose(mine, g_full[lo:hi], rtol=1e-13, atol=1e-15)
+        a1, b1_ = max(0, lo), min(ke, hi)                   # this rank's part of the knot group
+        a0, b0 = max(ke, lo), hi                            # ... of the MLP group
+        parts = torch.tensor([float((g_sh[a0:b0] ** 2).sum()) if b0 > a0 else 0.0,
+                              float((g_sh[a1:b1_] ** 2).sum()) if b1_ > a1 else 0.0], dtype=torch.float64)
+        D.allreduce_gradients(parts)
+        cm2 = min(1.0, clip / (float(parts[0].sqrt()) + 1e-6))
+        ck2 = min(1.0, clip_k / (float(parts[1].sqrt()) + 1e-6)) if ke else 1.0
+        assert abs(cm2 - cm) < 1e-12 and abs(ck2 - ck) < 1e-12
+        flat = p_all.clone()
+        ema_sh = p_all[lo:hi].clone()
+        zs = torch.zeros(chunk, dtype=torch.float64)
+        if b1_ > a1:
+            flat[a1:b1_], _, _, ema_sh[a1 - lo:b1_ - lo] = adam(p_all[a1:b1_], g_sh[a1:b1_], zs[a1 - lo:b1_ - lo],
+                                                               zs[a1 - lo:b1_ - lo], p_all[a1:b1_], ck2, lr_k)
+        if b0 > a0:
+            flat[a0:b0], _, _, ema_sh[a0 - lo:b0 - lo] = adam(p_all[a0:b0], g_sh[a0:b0], zs[a0 - lo:b0 - lo],
+                                                              zs[a0 - lo:b0 - lo], p_all[a0:b0], cm2, lr)
+        D.allgather_parameters(flat, flat[lo:hi].clone())
+        assert torch.allclose(flat, ref, rtol=1e-12, atol=1e-14)
+        ema_all = torch.empty(n, dtype=torch.float64)
+        D.allgather_parameters(ema_all, ema_sh)
+        assert torch.allclose(ema_all, ref_e, rtol=1e-12, atol=1e-14)
+        assert float(flat[P:].abs().sum()) == 0.0           # the padding stays zero
+        q.put((rank, float(flat.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P,ke", [(1000, 0), (1000, 90), (777, 600), (4096, 2048)])
+def test_sharded_optimizer_pattern_equals_replicated_gloo(P, ke):
+    """ke = size of the knot group at the head of the flat buffer: inside rank 0's slice (90), across the slice
+    boundary (600 of 777 -> slices of 416), exactly on it (2048)."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, P, ke, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert abs(res[0][1] - res[1][1]) < 1e-9              # both ranks hold the same gathered parameters

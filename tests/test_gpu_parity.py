@@ -465,11 +465,19 @@ def test_window_full_batch_sizes():
         yp = m(*(torch.from_numpy(a).to(d) for a in (X, coords, t)))
         loss = torch.nn.MSELoss()(yp, torch.from_numpy(y).to(d))
         loss.backward()
-        yo, lo, go = orc.train_step_grads(X, coords, t, y, params, cfg)
+        # 20 000 rows x 640 hidden units: a unit whose ReLU input the float64 run puts within 1e-6 of the kink can
+        # fall on the other side in ANY fp32 evaluation (y moves by <= 1e-6, that unit's gradient contribution by
+        # its full size: ~1e-5 of the gradient norms here; seed 98 has one within 1e-7).  Either side is accepted
+        # for exactly those units (fitted from the residual), nothing else.
+        yo, lo, go, alts = orc.train_step_grads(X, coords, t, y, params, cfg, kink_tol=1e-6)
         assert np.abs(yp.detach().cpu().numpy() - yo).max() <= TOL * max(1.0, np.abs(yo).max())
         assert abs(loss.item() - lo) <= TOL * lo
-        for k, p in m.named_parameters():
-            assert rel_l2(p.grad.cpu().numpy(), go[k]) <= TOL, k
+        got = {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}
+        flipped, adj = orc.fit_kink_sides(got, go, alts)
+        worst = max(rel_l2(got[k], adj[k]) for k in got)
+        print(f"B={B}: {len(alts)} hidden units within 1e-6 of a ReLU kink, on the other side in fp32: {flipped}; "
+              f"worst gradient rel-L2 {worst:.2e} (float64 sides: {max(rel_l2(got[k], go[k]) for k in got):.2e})")
+        assert worst <= TOL, (worst, flipped)
 
 
 # ------------------------------------------------------------------ fused engine (TrainStep / Predictor)

@@ -253,8 +253,10 @@ def test_n3_host_surface():
     # pointer to the bf16 shadow table
     assert ctypes.sizeof(N.AdamGroup) == 96 and N.AdamGroup.lr_dev.offset == 56 and N.AdamGroup.n_parts.offset == 80
     assert N.AdamGroup.shadow.offset == 88
-    # stdadk_optim_desc: 5 pointers, int64, float (+pad), pointer, 4 floats, pointer, float (+pad), pointer, float (+pad)
-    assert ctypes.sizeof(N.OptimDesc) == 120 and N.OptimDesc.step_dev.offset == 80 and N.OptimDesc.sumsq_parts.offset == 96
+    # stdadk_optim_desc: 5 pointers, int64, float (+pad), pointer, 4 floats, pointer, float (+pad), pointer, float (+pad),
+    # pointer to the bf16 shadow table, pointer to the non-finite guard word (ABI 7)
+    assert ctypes.sizeof(N.OptimDesc) == 128 and N.OptimDesc.step_dev.offset == 80 and N.OptimDesc.sumsq_parts.offset == 96
+    assert N.OptimDesc.shadow.offset == 112 and N.OptimDesc.nonfinite_step.offset == 120
     assert N.OptimDesc.shadow.offset == 112
     assert ctypes.sizeof(N.SparsityDesc) == 20 and N.SparsityDesc.apply_spatial.offset == 12
     # stdadk_knot_train: pointer, int32, 6 floats (+pad to 8)
@@ -397,3 +399,27 @@ def test_bench_record_helpers(tmp_path, monkeypatch):
     (tmp_path / "st-dadk_amd" / "csrc" / "k.hip").write_text("// kernel v2\n")            # any source change
     v, why = bench.pmc_traffic("l1_tail_kernel", "c2", B, "f32")
     assert v is None and "csrc_sha16" in why
+
+
+def test_bench_self_launch_starts_the_ranks_and_relays_failures(tmp_path, capfd):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: bench.self_launch starts N rank processes with the rendezvous
+    environment of torch.distributed.run (the parent never touches a GPU), rank 0 owns stdout, a failing rank stops
+    the others and its exit code is returned (the driver's N > 1 command died before any GPU call)."""
+    import bench
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(
+        "import os, sys, time\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert int(os.environ['MASTER_PORT']) > 0 and os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'\n"
+        "print('{\"rank\": %d, \"world\": %d, \"argv\": \"%s\"}' % (r, w, ' '.join(sys.argv[1:])))\n"
+        "if '--fail' in sys.argv and r == 1: sys.exit(7)\n"
+        "if '--fail' in sys.argv: time.sleep(60)\n")
+    assert bench.self_launch(3, ["--gpus", "3", "--steps", "5"], script=str(stub)) == 0
+    out, err = capfd.readouterr()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines == ['{"rank": 0, "world": 3, "argv": "--gpus 3 --steps 5"}']          # ONE line on stdout: rank 0's
+    assert '"rank": 1' in err and '"rank": 2' in err
+    t0 = __import__("time").perf_counter()
+    assert bench.self_launch(2, ["--fail"], script=str(stub)) == 7
+    assert __import__("time").perf_counter() - t0 < 30                                 # rank 0 was not waited for
