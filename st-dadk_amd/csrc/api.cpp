@@ -10,7 +10,11 @@
 
 #include "../../include/stdadk.h"
 
+#include <stdlib.h>
+
 namespace stdadk {
+// STDADK_DRY_RUN=1: validation and planning only, no HIP call (common.h)
+bool g_dry_run = [] { const char *e = getenv("STDADK_DRY_RUN"); return e && e[0] == '1'; }();
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
   va_list ap;

@@ -18,9 +18,16 @@ void set_error(const char *fmt, ...);
     }                                             \
   } while (0)
 
+// Host-side dry run (environment STDADK_DRY_RUN=1, read once when the library is loaded): every entry point runs its
+// argument validation, planning and job-table construction, and NO HIP call is made -- the launches and the LDS
+// attribute calls are skipped.  It exists for the host-side AddressSanitizer / UBSan pass (tools/build_asan.sh,
+// tests/test_host_sanitizer.py), which runs in a container without a GPU; pointers are never dereferenced on the host.
+extern bool g_dry_run;
+
 // Launch errors surface as positive hipError_t values.
 #define STDADK_CHECK_LAUNCH(what)                                             \
   do {                                                                        \
+    if (::stdadk::g_dry_run) break;                                           \
     hipError_t e__ = hipGetLastError();                                       \
     if (e__ != hipSuccess) {                                                  \
       ::stdadk::set_error("%s: %s", what, hipGetErrorString(e__));            \
@@ -35,6 +42,7 @@ void prof_after(hipStream_t st);
 extern bool g_prof_on;
 #define STDADK_LAUNCH(kern, grid, block, lds, st, ...)                         \
   do {                                                                        \
+    if (::stdadk::g_dry_run) break;                                           \
     if (::stdadk::g_prof_on) ::stdadk::prof_before(#kern, (st));              \
     hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);              \
     if (::stdadk::g_prof_on) ::stdadk::prof_after((st));                      \
@@ -42,10 +50,16 @@ extern bool g_prof_on;
 
 #define STDADK_LAUNCH_NAMED(name, kern, grid, block, lds, st, ...)              \
   do {                                                                        \
+    if (::stdadk::g_dry_run) break;                                           \
     if (::stdadk::g_prof_on) ::stdadk::prof_before((name), (st));             \
     hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);              \
     if (::stdadk::g_prof_on) ::stdadk::prof_after((st));                      \
   } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel (skipped in a dry run)
+static inline hipError_t set_max_dynamic_lds(const void *kernel, int bytes) {
+  return g_dry_run ? hipSuccess : hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -49,8 +49,7 @@ static int launch(const L1FwdArgs &l, const TailFwdArgs &f, const TailBwdArgs &b
   auto kern = l1_tail_kernel<CPL, LN, BASIS, FREE, BF>;
   static size_t attr_lds = 0;     // raised on the first (eager) call of a configuration, never under capture
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds);
     if (e != hipSuccess) { set_error("l1_tail: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_lds = lds;
   }
@@ -67,7 +66,6 @@ int l1_tail_launch(const L1FwdArgs &l_in, int basis, bool ln, const TailFwdArgs 
   TailFwdArgs f = f_in;
   TailBwdArgs b = b_in;
   f.krot = b.krot = tail_krot();
-  f.stagger_ticks = 0;
   STDADK_REQUIRE(l1_tail_supported(l.B, l.H) && f.B == l.B && b.B == l.B, STDADK_E_ARG,
                  "l1_tail: needs B <= 4096 and H in {128, 256}");
   STDADK_REQUIRE((int64_t)(l.g.p + l.g.Ks + l.g.Kt) * l.H < (1ll << 32), STDADK_E_ARG,

@@ -192,6 +192,7 @@ bool gemm_use_big_tile(int M, int N) {
 int gemm_pick_splits(int M, int N, int K, int *kps, bool big) {
   const int t = big ? 128 : 64;
   int64_t tiles = ceil_div(M, t) * ceil_div(N, t);
+  if (tiles < 1) tiles = 1;                 // an empty product still gets a (trivial) plan
   int s = 1;
   if (tiles < 256) s = (int)ceil_div(256, tiles);
   int max_s = (int)ceil_div(K, 4 * BK);   // at least 4 k-steps of work per split

@@ -548,6 +548,7 @@ static hipEvent_t *fork_events() {
 }
 // `to` waits for everything enqueued on `from` so far
 static int stream_depends(hipStream_t to, hipStream_t from, int slot) {
+  if (g_dry_run) return 0;
   hipEvent_t *ev = fork_events();
   STDADK_REQUIRE(ev != nullptr, STDADK_E_ARG, "could not create fork/join events");
   hipError_t e = hipEventRecord(ev[slot], from);
@@ -1063,7 +1064,9 @@ static int window_layer0_forward(Ctx &c, const stdadk_basis_desc *b, const float
 using namespace stdadk;
 
 extern "C" size_t stdadk_mlp_workspace_bytes(const stdadk_mlp_desc *desc, int64_t B) {
-  if (check_desc(desc) != 0 || B < 0) return 0;
+  // (a batch beyond the 32-bit row indices of the kernels is refused here too: the planner casts B to int, and the
+  //  host-side sanitizer pass found the division by zero a truncated 2^40 ran into)
+  if (check_desc(desc) != 0 || B < 0 || B >= (1ll << 31)) return 0;
   Plan p;
   make_plan(desc, B > 0 ? B : 1, &p);
   return p.total_floats * sizeof(float);
@@ -1128,7 +1131,7 @@ extern "C" int32_t stdadk_step_uses_window(const stdadk_basis_desc *b, const std
 
 extern "C" size_t stdadk_step_workspace_bytes(const stdadk_basis_desc *b, const stdadk_mlp_desc *d, int64_t B,
                                               int32_t flags) {
-  if (check_desc(d) != 0 || check_basis(b, d) != 0 || B < 0) return 0;
+  if (check_desc(d) != 0 || check_basis(b, d) != 0 || B < 0 || B >= (1ll << 31)) return 0;
   Plan p;
   make_plan(d, B > 0 ? B : 1, &p, want_window(b, d, flags) ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt,
             learn_ks(b, flags), is_scattered(b, flags) ? b->Ks : 0, b->n_levels);

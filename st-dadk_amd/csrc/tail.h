@@ -72,8 +72,6 @@ struct TailFwdArgs {
   const int *step_dev;
   int bf16;                     // STDADK_FLAG_BF16: the layers' GEMMs take bf16 operands (L[i].Wbf)
   int krot;                     // per-workgroup rotation of the K-chunk order (set by the launch code, tail_krot())
-  int stagger_ticks;            // 512-thread workgroups, two per CU: the later-placed one of the first round waits this
-                                // many 100 MHz ticks before it starts (set by the launch code; 0 = off)
   unsigned long long *stamps;   // -DSTDADK_DIAG builds only: [blocks][16] wall-clock stamps (100 MHz), else NULL
 };
 

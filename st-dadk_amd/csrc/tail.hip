@@ -39,21 +39,6 @@ template <int NW, int MT, bool D0, bool BF>
 __global__ TAIL_BOUNDS(NW) void tail_fwd_bwd_kernel(TailFwdArgs f, TailBwdArgs b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[NW];
-  if constexpr (NW == 8) {
-    // Two 512-thread workgroups share a CU.  Started together they run in lockstep -- both in a GEMM phase (sharing the
-    // matrix pipe), then both in a row-local phase (sharing the vector issue) -- which is one 1024-thread workgroup
-    // again.  The workgroup that got the HIGHER wave slots of its SIMDs (HW_ID.wave_id >= 2: the second one placed on
-    // the CU) therefore starts late by a fraction of a tile, in the first round of the grid only: one's GEMM phases
-    // then run beside the other's row-local phases (separate pipes).  Placement is only a speed matter: whatever
-    // the slots say, every workgroup computes its own tile.
-    if (f.stagger_ticks > 0 && blockIdx.x < 512) {
-      const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID[3:0] = wave slot
-      if (slot >= 2) {
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (unsigned long long)f.stagger_ticks) __builtin_amdgcn_s_sleep(32);
-      }
-    }
-  }
   Tail<NW>::template tail_fwd_body<MT, D0, BF>(f, smem, red, blockIdx.x);
   __syncthreads();
   Tail<NW>::template tail_bwd_body<MT, BF>(b, smem, blockIdx.x);
@@ -80,23 +65,11 @@ static size_t bwd_lds(int R, bool bf) {
   return (R == 64 ? T::template tail_bwd_lds_floats<4, false>() : (R == 32 ? T::template tail_bwd_lds_floats<2, false>() : T::template tail_bwd_lds_floats<1, false>())) * sizeof(float);
 }
 static_assert(Tail<16>::tail_bwd_lds_floats<4, true>() * sizeof(float) <= 160 * 1024, "bf16 backward tile does not fit the LDS");
-// measurement aid (round 3): STDADK_TAIL_WAVES=8 runs the fused forward + backward launch of large batches as 512-thread
-// workgroups on 32-row tiles, two per CU, the second one delayed by STDADK_TAIL_STAGGER_US microseconds
-static int tail_waves8() {
-  static const int on = [] { const char *e = getenv("STDADK_TAIL_WAVES"); return (e && atoi(e) == 8) ? 1 : 0; }();
-  return on;
-}
-static int tail_stagger_ticks() {
-  static const int t = [] { const char *e = getenv("STDADK_TAIL_STAGGER_US"); return e ? (int)(atof(e) * 100.0) : 0; }();
-  return t;
-}
-
 int tail_rows(int64_t B, bool cap32) {
   // two or four 16-row tiles per workgroup (shared weight fragments) once that still gives every CU
   // a workgroup; one tile per workgroup for small batches
   static const int forced = [] { const char *e = getenv("STDADK_TAIL_ROWS"); return e ? atoi(e) : 0; }();
   if (forced == 16 || forced == 32 || (forced == 64 && !cap32)) return forced;      // measurement aid
-  if (tail_waves8() && ceil_div(B, 32) >= 512) return 32;
   // (MI355X, C2 widths: 64 rows +5 % step throughput at B = 16 384 and 65 536 over 32 rows)
   if (ceil_div(B, 64) >= 256 && !cap32) return 64;
   return ceil_div(B, 32) >= 256 ? 32 : 16;
@@ -133,8 +106,7 @@ static int launch_fwd(const TailFwdArgs &a, hipStream_t st) {
   constexpr int R = 16 * MT, TT = 64 * NW;
   static bool attr_done = false;
   if (!attr_done) {   // once per process, never inside a stream capture (the first step runs eagerly)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel<NW, MT, D0, BF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds(R, D0, BF));
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void *>(tail_fwd_kernel<NW, MT, D0, BF>), (int)fwd_lds(R, D0, BF));
     if (e != hipSuccess) { set_error("tail_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
@@ -147,8 +119,12 @@ static int launch_fwd(const TailFwdArgs &a, hipStream_t st) {
 // dispatch on (rows, dense layer 0, bf16 operands); the bf16 + dense-0 combination is built for <= 32 rows.
 // All launches use Tail<16> (1024 threads, one workgroup per CU): Tail<8> -- 512 threads, 32-row tiles, TWO
 // workgroups per CU (confirmed by tools/diag/occupancy_tail8.hip), meant to overlap one tile's row-local phases with
-// the other's GEMM phases -- measured 0-4 % SLOWER at 16 384 and 65 536 rows, fp32 and bf16, so
-// it is not instantiated in the library.
+// the other's GEMM phases -- measured 0-4 % SLOWER at 16 384 and 65 536 rows, fp32 and bf16 (round 2), and again in
+// round 3 with the second workgroup of a CU started 3 .. 40 us late so that the two cannot run in lockstep: 451 us
+// (no delay) / 452 / 457 / 457 / 461 / 470 us against 448 us for one 1024-thread workgroup at 65 536 rows
+// (profiles/r03_tail_stagger_negative.txt).  The fp32 matrix instructions run at the fp32 VECTOR rate: a GEMM phase
+// and a row-local phase compete for the same issue, so there is nothing to overlap -- what pays is fewer vector
+// instructions in the row-local phases.  Tail<8> is not instantiated in the library.
 #define TAIL_DISPATCH(FN, r, d0, bf, ...)                                                                    \
   ((bf) ? ((d0) ? ((r) == 32 ? FN<16, 2, true, true>(__VA_ARGS__) : FN<16, 1, true, true>(__VA_ARGS__))      \
                 : ((r) == 64 ? FN<16, 4, false, true>(__VA_ARGS__)                                           \
@@ -166,7 +142,6 @@ int tail_krot() {
 int tail_forward(const TailFwdArgs &a_in, hipStream_t st) {
   TailFwdArgs a = a_in;
   a.krot = tail_krot();
-  a.stagger_ticks = 0;
   const bool d0 = a.d0.on != 0, bf = a.bf16 != 0;
   const int r = tail_rows(a.B, bf && d0);
   if (int rc = check_d0(a)) return rc;
@@ -179,8 +154,7 @@ static int launch_bwd(const TailBwdArgs &a, hipStream_t st) {
   constexpr int R = 16 * MT, TT = 64 * NW;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel<NW, MT, BF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<NW>(R, BF));
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void *>(tail_bwd_kernel<NW, MT, BF>), (int)bwd_lds<NW>(R, BF));
     if (e != hipSuccess) { set_error("tail_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
@@ -196,8 +170,7 @@ static int launch_fwd_bwd(const TailFwdArgs &f, const TailBwdArgs &b, hipStream_
   const size_t lds = fwd_lds(R, D0, BF) > bwd_lds<NW>(R, BF) ? fwd_lds(R, D0, BF) : bwd_lds<NW>(R, BF);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_bwd_kernel<NW, MT, D0, BF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void *>(tail_fwd_bwd_kernel<NW, MT, D0, BF>), (int)lds);
     if (e != hipSuccess) { set_error("tail_forward_backward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
@@ -218,11 +191,6 @@ int tail_forward_backward(const TailFwdArgs &f_in, const TailBwdArgs &b_in, hipS
   if (int rc = check_d0(f)) return rc;
   if (int rc = check_bf(f.bf16, f.n_layers, f.L, true, 0)) return rc;
   if (int rc = check_bf(b.bf16, b.n_layers, b.L, false, 1)) return rc;
-  f.stagger_ticks = 0;
-  if (tail_waves8() && r == 32 && !d0 && !bf && ceil_div(f.B, 32) >= 512) {
-    f.stagger_ticks = tail_stagger_ticks();
-    return launch_fwd_bwd<8, 2, false, false>(f, b, st);
-  }
   return TAIL_DISPATCH(launch_fwd_bwd, r, d0, bf, f, b, st);
 }
 

@@ -491,8 +491,7 @@ static int launch_fwd_t(const L1FwdArgs &a, hipStream_t st) {
   // capture: the engine runs its first step eagerly)
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds);
     if (e != hipSuccess) { set_error("l1_window_forward: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_lds = lds;
   }

@@ -232,10 +232,26 @@ def _check(rc, what):
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
 
 
+def dry_run():
+    """STDADK_DRY_RUN=1 (read by the library when it is loaded): every entry point validates and plans but launches
+    NOTHING -- the hook of the host-side sanitizer pass (tools/build_asan.sh, tests/test_host_sanitizer.py), which runs
+    without a GPU.  Host tensors are then accepted as stand-ins for device buffers (the host never dereferences
+    them); whatever comes out is meaningless.  Not a CPU path: without the variable host tensors raise."""
+    return os.environ.get("STDADK_DRY_RUN", "") == "1"
+
+
+def _on_device(tensor):
+    return tensor.is_cuda or dry_run()
+
+
 def _dev(tensor, name):
     """Validate a device tensor and return its address."""
     if tensor is None:
         return None
+    if dry_run() and not tensor.is_cuda:
+        if not tensor.is_contiguous():
+            raise RuntimeError(f"{name}: tensor must be contiguous")
+        return tensor.data_ptr()
     if not tensor.is_cuda:
         raise RuntimeError(f"{name}: expected a tensor on a HIP device (cuda:N), got {tensor.device}; "
                            f"the MI355X build of stnf has no CPU path")
@@ -252,6 +268,8 @@ def _dev(tensor, name):
 
 def _stream():
     """The current HIP stream of the current device (every tensor of a call is checked to live there)."""
+    if dry_run() and not torch.cuda.is_available():
+        return None
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -272,7 +290,7 @@ def rbf_build(coords, t, X, s_centers, s_bw, basis, t_centers, t_bw, out):
         raise RuntimeError(f"rbf_build: t must have {B} elements, got {t.numel()}")
     if p and X.shape[0] != B:
         raise RuntimeError("rbf_build: X row count mismatch")
-    if not out.is_cuda:
+    if not _on_device(out):
         raise RuntimeError("rbf_build: expected tensors on a HIP device; this build has no CPU path")
     rc = lib().stdadk_rbf_build_f32(
         _dev(coords, "coords") if Ks else None, _dev(t, "t") if Kt else None,
@@ -457,7 +475,7 @@ def loss(desc, y_pred, y, grad_scale, dY=None, loss_sum=None):
 
 def _rows(tensor, name, cols):
     """Address + row stride of a (Q, cols) fp32 device matrix whose rows are contiguous."""
-    if not tensor.is_cuda or tensor.dtype != torch.float32:
+    if not _on_device(tensor) or tensor.dtype != torch.float32:
         raise RuntimeError(f"{name}: expected a float32 tensor on a HIP device, got {tensor.dtype} on "
                            f"{tensor.device}; the MI355X build of stnf has no CPU path")
     if tensor.dim() != 2 or tensor.shape[1] != cols or (cols > 1 and tensor.stride(1) != 1):
@@ -560,7 +578,7 @@ def train_fwd_bwd_indexed(basis, desc, params, grads, coords_all, t_all, X_all, 
                           loss_sum, y_pred, workspace, flags, seed=0, step_dev=None, aux_stream=None,
                           loss_desc=None):
     """The fused step on rows `idx` (contiguous int64 device tensor) of the resident arrays (window path)."""
-    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+    if idx.dtype != torch.int64 or not _on_device(idx) or not idx.is_contiguous():
         raise RuntimeError("train_fwd_bwd_indexed: idx must be a contiguous int64 tensor on the device")
     rc = lib().stdadk_train_fwd_bwd_indexed_f32(
         C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads), _dev(coords_all, "coords"),
@@ -575,7 +593,7 @@ def train_fwd_bwd_indexed(basis, desc, params, grads, coords_all, t_all, X_all, 
 def bin_batch(basis, desc, coords_all, t_all, X_all, y_all, idx, workspace, flags):
     """Batch preparation of the window path on its own (rows `idx` of the resident arrays binned into
     `workspace`) on the current stream; the step then runs with FLAG_PREBINNED."""
-    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+    if idx.dtype != torch.int64 or not _on_device(idx) or not idx.is_contiguous():
         raise RuntimeError("bin_batch: idx must be a contiguous int64 tensor on the device")
     rc = lib().stdadk_bin_batch_f32(C.byref(basis), C.byref(desc), _dev(coords_all, "coords"), _dev(t_all, "t"),
                                     _dev(X_all, "X"), _dev(y_all, "y"), idx.data_ptr(), idx.numel(),
@@ -622,7 +640,7 @@ def knot_grad(coords, d_phi, centers, log_bw, basis, d_centers, d_log_bw):
 
 def gather_batch(coords, t, y, X, idx, coords_out, t_out, y_out, X_out):
     """Rows idx (int64 device tensor) of the resident observation arrays -> contiguous batch buffers."""
-    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+    if idx.dtype != torch.int64 or not _on_device(idx) or not idx.is_contiguous():
         raise RuntimeError("gather_batch: idx must be a contiguous int64 tensor on the device")
     B = idx.numel()
     Q = y.shape[1] if y is not None else 0
@@ -719,7 +737,7 @@ def train_step(basis, desc, params, grads, coords, t, X, y, idx, B, grad_scale, 
                seed=0, loss_desc=None, sparsity_desc=None):
     """The whole single-GPU step in one call: forward, objective (+ first-layer sparsity penalties), backward,
     clip + AdamW + EMA."""
-    if idx is not None and (idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous()):
+    if idx is not None and (idx.dtype != torch.int64 or not _on_device(idx) or not idx.is_contiguous()):
         raise RuntimeError("train_step: idx must be a contiguous int64 tensor on the device")
     rc = lib().stdadk_train_step_f32(
         C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads), _dev(coords, "coords"), _dev(t, "t"),

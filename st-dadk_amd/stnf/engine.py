@@ -175,7 +175,7 @@ class TrainStep:
         self._loss_descs = {}
         self.indexed_min_batch = _INDEXED_MIN_B
         self.dev = next(model.parameters()).device
-        if self.dev.type != "cuda":
+        if self.dev.type != "cuda" and not N.dry_run():
             raise RuntimeError("TrainStep needs the model on a HIP device; there is no CPU path")
         # distributed
         if distributed is None:
