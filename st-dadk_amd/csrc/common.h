@@ -103,20 +103,40 @@ __device__ __forceinline__ uint32_t mix32(uint64_t x) {
   return (uint32_t)x;
 }
 // Two stages: a 64-bit mix per (seed, layer, ROW) -- once per row, wave-uniform wherever a wave owns a row, so it
-// runs on the scalar unit -- and a 32-bit finisher per column (two multiplies, three xor-shifts).  The 64-bit mix
-// per ELEMENT that this replaced was ~40 vector instructions of the ~60 a LayerNorm-phase element costs: with four
-// rows per wave (64-row tiles) those phases were bound by vector issue, not by memory (round-2 stamps).
+// runs on the scalar unit -- and a 32-bit finisher (two multiplies, three xor-shifts) that serves TWO columns: the
+// columns c and c + 64 of a 128-column block share one hash, the low 16 bits decide the first, the high 16 bits the
+// second.  A lane of the row-local phases owns the columns lane + 64 cc, i.e. exactly such pairs: one finisher per two
+// elements (round 3; the finisher per element was ~13 of the ~40 vector instructions a LayerNorm-phase element cost,
+// two of them quarter-rate multiplies).  The 64-bit mix per ELEMENT of round 1 was ~40 on its own.
 __device__ __forceinline__ uint32_t drop_rowkey(uint64_t seed, int layer, int64_t row) {
   return mix32(seed ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(layer + 1)) ^ ((uint64_t)row * 0xD1B54A32D192ED03ULL));
 }
-// keep when u >= p for u = (h >> 8) / 2^24 uniform in [0,1), i.e. (h >> 8) >= ceil(p 2^24)   (P(keep) = 1-p)
-__device__ __forceinline__ uint32_t drop_threshold(float p) { return (uint32_t)ceilf(p * 16777216.0f); }
-__device__ __forceinline__ bool drop_keep(uint32_t rowkey, int col, uint32_t thr) {
-  uint32_t h = rowkey ^ ((uint32_t)col * 0x9E3779B1u);
+// keep when u >= p for u = v / 2^16 uniform in [0,1), v = the column's 16 bits: v >= ceil(p 2^16)   (P(keep) = 1-p)
+__device__ __forceinline__ uint32_t drop_threshold(float p) { return (uint32_t)ceilf(p * 65536.0f); }
+__device__ __forceinline__ int drop_pair(int col) { return (col & 63) | ((col >> 7) << 6); }
+__device__ __forceinline__ uint32_t drop_hash(uint32_t rowkey, int pair) {
+  uint32_t h = rowkey ^ ((uint32_t)pair * 0x9E3779B1u);
   h ^= h >> 16; h *= 0x21f0aaadu;
   h ^= h >> 15; h *= 0x735a2d97u;
   h ^= h >> 15;
-  return (h >> 8) >= thr;
+  return h;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t rowkey, int col, uint32_t thr) {
+  const uint32_t h = drop_hash(rowkey, drop_pair(col));
+  return (((col >> 6) & 1) ? (h >> 16) : (h & 0xffffu)) >= thr;
+}
+
+// LayerNorm statistics, the same expressions in every kernel that normalises a row (tail bodies, layer-0 window
+// bodies, the per-layer row kernels), so that the paths stay bitwise interchangeable:
+//   mean = sum * inv_n, var = sum of squared deviations * inv_n, with inv_n = 1.0f / n taken once per phase (an IEEE
+//   division per ROW was ~10 vector instructions; for the power-of-two widths of every shipped configuration the
+//   product equals the quotient bit for bit);
+//   rstd = 1 / sqrt(var + eps) from v_rsq_f32 (1 ulp) and one Newton step -- the correctly rounded sqrtf followed by
+//   an IEEE division was ~25 vector instructions per row.
+__device__ __forceinline__ float ln_rstd(float var, float eps) {
+  const float x = var + eps;
+  const float y = __builtin_amdgcn_rsqf(x);
+  return y * fmaf(-0.5f * x * y, y, 1.5f);
 }
 
 }  // namespace stdadk

@@ -300,11 +300,11 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) s += acc[c];
-      mean = wave_sum(s) / (float)H;
+      mean = wave_sum(s) * (1.0f / (float)H);
       float sq = 0.f;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) { float d = acc[c] - mean; sq += d * d; }
-      rs = 1.0f / sqrtf(wave_sum(sq) / (float)H + a.eps);
+      rs = ln_rstd(wave_sum(sq) * (1.0f / (float)H), a.eps);
       if (lane == 0 && a.rstd) a.rstd[row] = rs;
     }
     float xh[CPL], av[CPL];
@@ -580,11 +580,11 @@ __device__ __forceinline__ void l1_window_fwd_multi_body(const L1FwdArgs &a, flo
           float s = 0.f;
 #pragma unroll
           for (int c = 0; c < CPL; ++c) s += acc[r][c];
-          mean = wave_sum(s) / (float)H;
+          mean = wave_sum(s) * (1.0f / (float)H);
           float sq = 0.f;
 #pragma unroll
           for (int c = 0; c < CPL; ++c) { float d = acc[r][c] - mean; sq += d * d; }
-          rs = 1.0f / sqrtf(wave_sum(sq) / (float)H + a.eps);
+          rs = ln_rstd(wave_sum(sq) * (1.0f / (float)H), a.eps);
           if (lane == 0 && a.rstd) a.rstd[orow] = rs;
         }
         typename VecT<CPL>::T o1, o2;

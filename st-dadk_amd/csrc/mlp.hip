@@ -196,13 +196,14 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_fwd_kernel(
   }
   float rs = 1.f, mean = 0.f;
   if (LN) {
-    mean = wave_sum(sum) / (float)h;
+    const float inv_h = 1.0f / (float)h;
+    mean = wave_sum(sum) * inv_h;
     float sq = 0.f;
 #pragma unroll
     for (int j = 0; j < CPL; ++j)
       if (lane + 64 * j < h) { float d = z[j] - mean; sq += d * d; }
-    float var = wave_sum(sq) / (float)h;
-    rs = 1.0f / sqrtf(var + eps);
+    float var = wave_sum(sq) * inv_h;
+    rs = ln_rstd(var, eps);
     if (lane == 0) rstd_out[row] = rs;
   }
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -275,8 +276,9 @@ __global__ __launch_bounds__(ROW_T) void ln_relu_bwd_kernel(
     }
     float rs = 1.f, m1 = 0.f, m2 = 0.f;
     if (LN) {
-      m1 = wave_sum(s1) / (float)h;
-      m2 = wave_sum(s2) / (float)h;
+      const float inv_h = 1.0f / (float)h;
+      m1 = wave_sum(s1) * inv_h;
+      m2 = wave_sum(s2) * inv_h;
       rs = rstd[row];
     }
 #pragma unroll

@@ -316,6 +316,195 @@ static __device__ __forceinline__ void d0_gemm(f32x4 (*acc)[MAX_NI], const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// row-local phases of a layer, one wave per RPW rows of the tile, lane l owning the columns l + 64 cc
+// ---------------------------------------------------------------------------------------------
+// Specialised on the layer's width: CC = 64-column groups a lane walks, FULL = the width is exactly 64 CC.  With FULL
+// nothing is masked: no select per element, and -- what cost more -- no exec-masked branch around every store (the
+// compiler turns `if (column < h) store` into a save-exec / branch / restore block per store: twelve per row in the
+// forward phase).  A 128-wide layer walks two groups instead of four masked ones.  The generic instantiation
+// (CC = 4, masks) keeps every other width working.  Same arithmetic, in the same order, in all of them.
+struct LnFwdCtx {
+  float *xhat, *act, *rstd;      // NULL in eval mode
+  int layer_id, h, B;
+  float eps;
+  uint64_t seed;
+  float keep_scale;
+  uint32_t drop_thr;
+  bool drop_on, ln_on;
+};
+
+template <int RPW, int CC, bool FULL, bool BF>
+static __device__ __forceinline__ void ln_fwd_rows(const LnFwdCtx &c, float *nxt, u16 *abf, int wave, int lane, int row0,
+                                                   const float (&gv)[4], const float (&bev)[4]) {
+  const int h = c.h;
+  bool okc[CC];
+#pragma unroll
+  for (int cc = 0; cc < CC; ++cc) okc[cc] = FULL || lane + 64 * cc < h;
+  const float inv_h = 1.0f / (float)h;
+  float z[RPW][CC], mean[RPW], rs[RPW];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const float *zp = nxt + (RPW * wave + rr) * ACT_LD + lane;      // lane + 64 cc < 256 <= ACT_LD: in the row
+    float sm = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+      const float t = zp[64 * cc];
+      z[rr][cc] = okc[cc] ? t : 0.f;
+      sm += z[rr][cc];
+    }
+    mean[rr] = sm;
+  }
+  if (c.ln_on) {
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) mean[rr] = wave_sum(mean[rr]) * inv_h;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      float sq = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc) {
+        const float d = okc[cc] ? z[rr][cc] - mean[rr] : 0.f;
+        sq += d * d;
+      }
+      rs[rr] = sq;
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) rs[rr] = ln_rstd(wave_sum(rs[rr]) * inv_h, c.eps);
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) { mean[rr] = 0.f; rs[rr] = 1.f; }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = RPW * wave + rr;
+    const int grow = row0 + row;
+    float xh[CC], v[CC];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+      xh[cc] = c.ln_on ? (z[rr][cc] - mean[rr]) * rs[rr] : z[rr][cc];
+      v[cc] = fmaxf(fmaf(xh[cc], gv[cc], bev[cc]), 0.f);
+    }
+    if (c.drop_on) {
+      const uint32_t rowkey = drop_rowkey(c.seed, c.layer_id, grow);
+#pragma unroll
+      for (int pp = 0; pp < (CC + 1) / 2; ++pp) {                 // columns lane + 128 pp and + 64: one hash
+        const uint32_t hh = drop_hash(rowkey, lane + 64 * pp);
+        v[2 * pp] = (hh & 0xffffu) >= c.drop_thr ? v[2 * pp] * c.keep_scale : 0.f;
+        if (2 * pp + 1 < CC) v[2 * pp + 1] = (hh >> 16) >= c.drop_thr ? v[2 * pp + 1] * c.keep_scale : 0.f;
+      }
+    }
+    float *np = nxt + row * ACT_LD + lane;
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc)
+      if (FULL || okc[cc]) np[64 * cc] = v[cc];
+    if constexpr (BF) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)      // every column of the image up to 255: zero beyond the layer's width
+        abf[row * ABF_LD + lane + 64 * cc] = (cc < CC && okc[cc < CC ? cc : 0]) ? to_bf16(v[cc < CC ? cc : 0]) : (u16)0;
+    }
+    if (c.xhat != nullptr && grow < c.B) {        // both wave-uniform
+      float *xp = c.xhat + (size_t)grow * h + lane, *ap = c.act + (size_t)grow * h + lane;
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc)
+        if (FULL || okc[cc]) { xp[64 * cc] = xh[cc]; ap[64 * cc] = v[cc]; }
+      if (c.ln_on && c.rstd != nullptr && lane == 0) c.rstd[grow] = rs[rr];
+    }
+  }
+}
+
+struct LnBwdCtx {
+  float *dz;                     // [B][h] out
+  int layer_id, h, B;
+  uint64_t seed;
+  float keep_scale;
+  uint32_t drop_thr;
+  bool drop_on, ln_on;
+};
+
+// Dropout -> ReLU -> LayerNorm backward of the wave's rows: dZ into `cur` (in place over dA), into the bf16 image and
+// into global memory; the wave's column partials of dgamma / dbeta / db are ADDED into pg / pb / pz (entries >= CC
+// untouched).  Staged over the rows like the forward phase: the masked gradient and the two row sums of every row,
+// then the rows' reductions (independent chains), then dZ and its stores.
+template <int RPW, int CC, bool FULL, bool BF>
+static __device__ __forceinline__ void ln_bwd_rows(const LnBwdCtx &c, float *cur, u16 *abf, int wave, int lane, int row0,
+                                                   const float (&gv)[4], const float (&bev)[4], const float (&xv)[RPW][4],
+                                                   const float (&rsv)[RPW], float (&pg)[4], float (&pb)[4], float (&pz)[4]) {
+  const int h = c.h;
+  bool okc[CC];
+#pragma unroll
+  for (int cc = 0; cc < CC; ++cc) okc[cc] = FULL || lane + 64 * cc < h;
+  const float inv_h = 1.0f / (float)h;
+  float dxh[RPW][CC], m1[RPW], m2[RPW];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = RPW * wave + rr;
+    const int grow = row0 + row;
+    const bool valid = grow < c.B;                       // scalar
+    const float *cp = cur + row * ACT_LD + lane;         // lane + 64 cc < 256 <= ACT_LD: in the row
+    float d[CC];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) d[cc] = cp[64 * cc];
+    if (c.drop_on) {
+      const uint32_t rowkey = drop_rowkey(c.seed, c.layer_id, grow);
+#pragma unroll
+      for (int pp = 0; pp < (CC + 1) / 2; ++pp) {
+        const uint32_t hh = drop_hash(rowkey, lane + 64 * pp);
+        d[2 * pp] = (hh & 0xffffu) >= c.drop_thr ? d[2 * pp] * c.keep_scale : 0.f;
+        if (2 * pp + 1 < CC) d[2 * pp + 1] = (hh >> 16) >= c.drop_thr ? d[2 * pp + 1] * c.keep_scale : 0.f;
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+      const float x = xv[rr][cc];
+      const float u = fmaf(x, gv[cc], bev[cc]);
+      float dd = (valid && okc[cc] && u > 0.f) ? d[cc] : 0.f;
+      if (c.ln_on) {
+        pg[cc] += dd * x;
+        pb[cc] += dd;
+        dd *= gv[cc];
+        s1 += dd;
+        s2 += dd * x;
+      }
+      dxh[rr][cc] = dd;
+    }
+    m1[rr] = s1; m2[rr] = s2;
+  }
+  if (c.ln_on) {
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) m1[rr] = wave_sum(m1[rr]) * inv_h;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) m2[rr] = wave_sum(m2[rr]) * inv_h;
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = RPW * wave + rr;
+    const int grow = row0 + row;
+    const bool valid = grow < c.B;
+    float dz[CC];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+      dz[cc] = (c.ln_on && valid) ? rsv[rr] * (dxh[rr][cc] - m1[rr] - xv[rr][cc] * m2[rr]) : dxh[rr][cc];
+      if (FULL || okc[cc]) pz[cc] += dz[cc];
+    }
+    float *cw = cur + row * ACT_LD + lane;
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc)
+      if (FULL || okc[cc]) cw[64 * cc] = dz[cc];
+    if constexpr (BF) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)      // columns h .. 255 of the image: zero (64-deep chunks)
+        abf[row * ABF_LD + lane + 64 * cc] = (cc < CC && okc[cc < CC ? cc : 0]) ? to_bf16(dz[cc < CC ? cc : 0]) : (u16)0;
+    }
+    if (valid) {
+      float *gp = c.dz + (size_t)grow * h + lane;
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc)
+        if (FULL || okc[cc]) gp[64 * cc] = dz[cc];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 // BF: the layers' GEMMs take bf16 operands (fp32 accumulate; LayerNorm, loss and everything kept for the backward
@@ -454,80 +643,12 @@ static __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float
     }
     lds_barrier();
     STAMP(3 + 4 * (li < 0 ? 0 : li));
-    // LayerNorm -> ReLU -> Dropout, wave w owns rows RPW*w .. RPW*w+RPW-1.  Written as stages over the wave's rows:
-    // everything the phase needs from the argument block is in registers before its first store (the stores are
-    // conditional, and the compiler otherwise fetches the pointers under each condition: a scalar load + wait per
-    // element); the rows' two reductions are independent chains; a row's stores go out together.  Same arithmetic,
-    // in the same order, as a row at a time.
+    // LayerNorm -> ReLU -> Dropout of the wave's rows, specialised on the layer's width (ln_fwd_rows below)
     {
-      float *const xhat_p = L.xhat, *const act_p = L.act, *const rstd_p = L.rstd;     // NULL in eval mode
-      const int lid = L.layer_id;
-      bool okc[4];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) okc[cc] = lane + 64 * cc < h;
-      float z[RPW][4], mean[RPW], rs[RPW];
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const float *zp = nxt + (RPW * wave + rr) * ACT_LD + lane;      // lane + 64 cc < 256 <= ACT_LD: in the row
-        float sm = 0.f;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const float t = zp[64 * cc];
-          z[rr][cc] = okc[cc] ? t : 0.f;
-          sm += z[rr][cc];
-        }
-        mean[rr] = sm;
-      }
-      if (ln_on) {
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) mean[rr] = wave_sum(mean[rr]) / (float)h;
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-          float sq = 0.f;
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const float d = okc[cc] ? z[rr][cc] - mean[rr] : 0.f;
-            sq += d * d;
-          }
-          rs[rr] = sq;
-        }
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) rs[rr] = 1.0f / sqrtf(wave_sum(rs[rr]) / (float)h + a.eps);
-      } else {
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) { mean[rr] = 0.f; rs[rr] = 1.f; }
-      }
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = RPW * wave + rr;
-        const int grow = row0 + row;
-        float xh[4], v[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          xh[cc] = ln_on ? (z[rr][cc] - mean[rr]) * rs[rr] : z[rr][cc];
-          v[cc] = fmaxf(fmaf(xh[cc], gv[cc], bev[cc]), 0.f);
-        }
-        if (drop_on) {
-          const uint32_t rowkey = drop_rowkey(seed, lid, grow);
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) v[cc] = drop_keep(rowkey, lane + 64 * cc, drop_thr) ? v[cc] * keep_scale : 0.f;
-        }
-        float *np = nxt + row * ACT_LD + lane;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-          if (okc[cc]) np[64 * cc] = v[cc];
-        if constexpr (BF) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) abf[row * ABF_LD + lane + 64 * cc] = okc[cc] ? to_bf16(v[cc]) : (u16)0;     // next layer's A operand
-        }
-        if (xhat_p != nullptr && grow < a.B) {        // both wave-uniform
-          float *xp = xhat_p + (size_t)grow * h + lane, *ap = act_p + (size_t)grow * h + lane;
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc)
-            if (okc[cc]) { xp[64 * cc] = xh[cc]; ap[64 * cc] = v[cc]; }
-          if (ln_on && rstd_p != nullptr && lane == 0) rstd_p[grow] = rs[rr];
-        }
-      }
+      const LnFwdCtx c{L.xhat, L.act, L.rstd, L.layer_id, h, a.B, a.eps, seed, keep_scale, drop_thr, drop_on, ln_on};
+      if (h == 256) ln_fwd_rows<RPW, 4, true, BF>(c, nxt, abf, wave, lane, row0, gv, bev);
+      else if (h == 128) ln_fwd_rows<RPW, 2, true, BF>(c, nxt, abf, wave, lane, row0, gv, bev);
+      else ln_fwd_rows<RPW, 4, false, BF>(c, nxt, abf, wave, lane, row0, gv, bev);
     }
     STAMP(4 + 4 * (li < 0 ? 0 : li));
     lds_barrier();
@@ -770,84 +891,16 @@ static __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float
       if constexpr (BF) preload_wh(wpre_h, L.WTbf, L.hp, h, wave, c16, q, rot);
       else preload_w<true>(wpre, L.W, L.hp, h, wave, c16, q, rot);
     }
-    // ---- (a) Dropout -> ReLU -> LayerNorm backward, rows RPW*w .. of this wave.  Its global inputs
-    // (xhat rows, gamma, beta, rstd) were requested one phase early (ln_inputs below).
-    // Staged over the wave's rows like the forward phase: the masked gradient and the two row sums of every row,
-    // then the rows' reductions (independent chains), then dZ and its stores.
+    // ---- (a) Dropout -> ReLU -> LayerNorm backward of the wave's rows, specialised on the layer's width
+    // (ln_bwd_rows below).  Its global inputs (xhat rows, gamma, beta, rstd) were requested one phase early (ln_inputs).
     float pg[4], pb[4], pz[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) pg[cc] = pb[cc] = pz[cc] = 0.f;
     {
-      float *const dz_p = a.dZ[li];
-      const int lid = L.layer_id;
-      bool okc[4];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) okc[cc] = lane + 64 * cc < h;
-      float dxh[RPW][4], m1[RPW], m2[RPW];
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = RPW * wave + rr;
-        const int grow = row0 + row;
-        const bool valid = grow < a.B;                       // scalar
-        const float *cp = cur + row * ACT_LD + lane;        // lane + 64 cc < 256 <= ACT_LD: in the row
-        float d[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) d[cc] = cp[64 * cc];
-        if (drop_on) {
-          const uint32_t rowkey = drop_rowkey(seed, lid, grow);
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) d[cc] = drop_keep(rowkey, lane + 64 * cc, drop_thr) ? d[cc] * keep_scale : 0.f;
-        }
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const float x = xv[rr][cc];
-          const float u = fmaf(x, gv[cc], bev[cc]);
-          float dd = (valid && okc[cc] && u > 0.f) ? d[cc] : 0.f;
-          if (ln_on) {
-            pg[cc] += dd * x;
-            pb[cc] += dd;
-            dd *= gv[cc];
-            s1 += dd;
-            s2 += dd * x;
-          }
-          dxh[rr][cc] = dd;
-        }
-        m1[rr] = s1; m2[rr] = s2;
-      }
-      if (ln_on) {
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) m1[rr] = wave_sum(m1[rr]) / (float)h;
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) m2[rr] = wave_sum(m2[rr]) / (float)h;
-      }
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = RPW * wave + rr;
-        const int grow = row0 + row;
-        const bool valid = grow < a.B;
-        float dz[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          dz[cc] = (ln_on && valid) ? rsv[rr] * (dxh[rr][cc] - m1[rr] - xv[rr][cc] * m2[rr]) : dxh[rr][cc];
-          if (okc[cc]) pz[cc] += dz[cc];
-        }
-        float *cw = cur + row * ACT_LD + lane;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-          if (okc[cc]) cw[64 * cc] = dz[cc];
-        if constexpr (BF) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc)      // columns h .. 255 of the image: zero (64-deep chunks)
-            abf[row * ABF_LD + lane + 64 * cc] = okc[cc] ? to_bf16(dz[cc]) : (u16)0;
-        }
-        if (valid) {
-          float *gp = dz_p + (size_t)grow * h + lane;
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc)
-            if (okc[cc]) gp[64 * cc] = dz[cc];
-        }
-      }
+      const LnBwdCtx c{a.dZ[li], L.layer_id, h, a.B, seed, keep_scale, drop_thr, drop_on, ln_on};
+      if (h == 256) ln_bwd_rows<RPW, 4, true, BF>(c, cur, abf, wave, lane, row0, gv, bev, xv, rsv, pg, pb, pz);
+      else if (h == 128) ln_bwd_rows<RPW, 2, true, BF>(c, cur, abf, wave, lane, row0, gv, bev, xv, rsv, pg, pb, pz);
+      else ln_bwd_rows<RPW, 4, false, BF>(c, cur, abf, wave, lane, row0, gv, bev, xv, rsv, pg, pb, pz);
     }
     // column partials of this workgroup's rows (`nxt` is not read again before the GEMM below refills it)
     float *red = RED_ALIAS ? nxt : red_own;

@@ -150,7 +150,7 @@ def _dp3_worker(rank, world, port, sizes, B, learn, shard, q):
                 for p in m.parameters():
                     p.add_(0.01 * torch.randn_like(p))
             torch.manual_seed(777)
-        eng = TrainStep(m, lr=1e-3, ema_decay=0.9, max_batch=B, shard_optimizer=shard, **kw)
+        eng = TrainStep(m, lr=1e-3, eps=R2._DP_EPS, ema_decay=0.9, max_batch=B, shard_optimizer=shard, **kw)
         assert eng.distributed and eng.world == world and eng.rank == rank and eng.shard == shard
         seeds = [None, None]
         dist.all_gather_object(seeds, eng.base_seed)
@@ -193,7 +193,7 @@ def test_two_rank_epochs_sharded_optimizer_and_synchronised_init(learn, shard):
     assert steps == 2 * len(table)
     m, kw = R2._dp_model(learn)
     # dropout streams: the single process cannot reproduce two ranks' masks -- the model cases have dropout 0
-    eng = TrainStep(m, lr=1e-3, ema_decay=0.9, max_batch=2 * B, **kw)
+    eng = TrainStep(m, lr=1e-3, eps=R2._DP_EPS, ema_decay=0.9, max_batch=2 * B, **kw)
     for _ in range(2):
         off = [0, sizes[0]]
         for row in table:
