@@ -59,8 +59,13 @@ struct BFragH { uint4 v[2 * NI]; };     // [2*i + half]: this lane's 16 k of wei
 
 #ifdef STDADK_DIAG   // diagnostic build only: in-kernel wall-clock stamps of the phases
 #define STAMP(i) do { if (a.stamps && tid == 0) a.stamps[tile * 16 + (i)] = wall_clock64(); } while (0)
+// per-WAVE stamps of the first GEMM phase of the 64-row forward (MT = 4): the stamp buffer of tools/stamp_tail.py holds
+// B/16 x 16 slots, the 64-row tiles use the first quarter, [tile][wave][3] goes behind it
+#define WSTAMP(i) do { if (MT == 4 && a.stamps && lane == 0) \
+  a.stamps[(size_t)((a.B + 63) / 64) * 16 + ((size_t)tile * 16 + wave) * 3 + (i)] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define WSTAMP(i) do { } while (0)
 #endif
 
 template <int NW_>
@@ -138,6 +143,31 @@ static __device__ __forceinline__ void mma_chunk(f32x4 (*acc)[MAX_NI], const BFr
 // r2 item 3): no gain -- off by default (rot = 0 is the natural order), kept as a switch for that measurement.
 static __device__ __forceinline__ int chunk_start(int rot, int nchunk) { return rot % nchunk; }
 
+// mma_chunk for a chunk that lies entirely below K (no scalar test per 16-deep half: straight-line code)
+template <int NI, int MT>
+static __device__ __forceinline__ void mma_chunk_full(f32x4 (*acc)[MAX_NI], const BFrag<MAX_NI> &f, const float *__restrict__ A,
+                                                      int c, int c16, int q) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float af[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float4 av = *reinterpret_cast<const float4 *>(A + (16 * mt + c16) * ACT_LD + 32 * c + 16 * j + 4 * q);
+      af[mt][0] = av.x; af[mt][1] = av.y; af[mt][2] = av.z; af[mt][3] = av.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const float4 bv = f.v[2 * i + j];
+        const float bf[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][i] = mfma16(af[mt][e], bf[e], acc[mt][i]);
+      }
+    }
+  }
+}
+
 // The first 32-deep weight chunk of a GEMM phase, requested one phase EARLY (before the row-local
 // LayerNorm / input phase that precedes the GEMM) so that its L2 round trip is hidden behind that phase.
 // `rot`: this workgroup's rotation of the K-chunk order (chunk_start above), 0 = natural order.
@@ -172,12 +202,41 @@ static __device__ __forceinline__ void gemm16_loop(f32x4 (*acc)[MAX_NI], const f
     }
   }
 }
+// K = 32 NCH exactly (the widths 256 and 128 of every shipped configuration), natural chunk order: the chunk loop
+// fully unrolled over a ring of three fragment buffers, chunks c + 1 and c + 2 in flight while chunk c is multiplied.
+// Straight-line code matters here: in the rolled loop above the loads of the next chunk sit behind a scalar branch
+// (the last chunk has no successor), and where the two paths meet the compiler can only wait for the larger of their
+// outstanding-load counts -- s_waitcnt vmcnt(1) / vmcnt(0) right behind the loads it has just issued (ROCm 7.2), i.e.
+// every chunk's MFMAs waited for the NEXT chunk's fragments: no weight chunk was ever in flight under the MFMAs, and
+// the phase ran at ~60-70 % of the matrix pipe with four waves per SIMD covering for each other (round-3 per-wave
+// stamps, tools/diag/wave_stamps.py).  Unrolled, every wait is an exact count.
+template <int MT, int NI, bool KN, int NCH>
+static __device__ __forceinline__ void gemm16_unrolled(f32x4 (*acc)[MAX_NI], const float *__restrict__ A,
+                                                       const float *__restrict__ W, int N, int K, int wave, int c16,
+                                                       int q, const BFrag<MAX_NI> &f0) {
+  // (also measured: the A fragments of the next 16-deep step read from LDS ahead of the current step's MFMAs, two
+  //  register sets -- 56.8 vs 57.3 us for the 16-row fused kernel, 403 vs 388 us at 64 rows; and that order pinned
+  //  with sched_group_barrier -- 59.8 / 407 us: the compiler's own placement of the LDS reads stays)
+  BFrag<MAX_NI> f[3];
+  f[0] = f0;
+  if (NCH > 1) load_bfrag<NI, KN>(f[1], W, N, K, 1, wave, c16, q);
+  if (NCH > 2) load_bfrag<NI, KN>(f[2], W, N, K, 2, wave, c16, q);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    mma_chunk_full<NI, MT>(acc, f[c % 3], A, c, c16, q);
+    if (c + 3 < NCH) load_bfrag<NI, KN>(f[c % 3], W, N, K, c + 3, wave, c16, q);
+  }
+}
+
 template <int MT, bool KN = false>
 static __device__ __forceinline__ void gemm16_pre(f32x4 (*acc)[MAX_NI], const float *__restrict__ A,
                                                   const float *__restrict__ W, int N, int K, int wave, int c16,
                                                   int q, BFrag<MAX_NI> &f0, int rot = 0) {
   if (wave >= (N >> 4)) return;                 // scalar: this wave has no N tile in a narrow layer
+
   if (MAX_NI > 1 && tiles_of(N) > 1) gemm16_loop<MT, MAX_NI, KN>(acc, A, W, N, K, wave, c16, q, f0, rot);
+  else if (MAX_NI == 1 && rot == 0 && K == 256) gemm16_unrolled<MT, 1, KN, 8>(acc, A, W, N, K, wave, c16, q, f0);
+  else if (MAX_NI == 1 && rot == 0 && K == 128) gemm16_unrolled<MT, 1, KN, 4>(acc, A, W, N, K, wave, c16, q, f0);
   else gemm16_loop<MT, 1, KN>(acc, A, W, N, K, wave, c16, q, f0, rot);
 }
 
@@ -595,6 +654,11 @@ static __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float
       gv[cc] = a.layernorm ? L.g[colc] : 1.f;
       bev[cc] = a.layernorm ? L.be[colc] : 0.f;
     }
+    // this wave's bias columns: requested before the GEMM like the LayerNorm parameters (it used to be a dependent
+    // L2 round trip between the last MFMA and the stores of z: ~1 us per layer at the tail of every wave)
+    float bias_v[MAX_NI];
+#pragma unroll
+    for (int i = 0; i < MAX_NI; ++i) bias_v[i] = L.b[min(16 * (wave + NW * i), h - 16) + c16];
     f32x4 acc[MT][MAX_NI];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -620,8 +684,10 @@ static __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float
         if (hp > TAIL_MAX_W) lds_barrier();      // z goes into act1, which held the second half of the features
       }
     } else {
+      if (li == 0) WSTAMP(0);
       if constexpr (BF) gemm16_pre_h<MT>(acc, abf, L.Wbf, h, hp, wave, c16, q, wpre_h, rot);
       else gemm16_pre<MT>(acc, cur, L.W, h, hp, wave, c16, q, wpre, rot);
+      if (li == 0) WSTAMP(1);
     }
     if (li + 1 < a.n_layers) {
       if constexpr (BF) preload_wh(wpre_h, a.L[li + 1].Wbf, a.L[li + 1].h, a.L[li + 1].hp, wave, c16, q, rot);
@@ -634,13 +700,14 @@ static __device__ __forceinline__ void tail_fwd_body(const TailFwdArgs &a, float
       const int t = wave + NW * i;
       if (t < NT && !parts) {
         const int col = 16 * t + c16;
-        const float bv = L.b[col];
+        const float bv = bias_v[i];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) nxt[(16 * mt + 4 * q + r) * ACT_LD + col] = acc[mt][i][r] + bv;
       }
     }
+    if (li == 0) WSTAMP(2);
     lds_barrier();
     STAMP(3 + 4 * (li < 0 ? 0 : li));
     // LayerNorm -> ReLU -> Dropout of the wave's rows, specialised on the layer's width (ln_fwd_rows below)
