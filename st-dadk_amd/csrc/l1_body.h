@@ -110,6 +110,40 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
       }
     };
 
+    // The same gather-FMA over a list zero-padded to a multiple of 16, software-pipelined: the eight rows of group
+    // g + 1 are requested before the multiply-adds of group g (two register sets), so the ~8 groups of an observation
+    // cost about one L2 round trip plus their FMAs instead of one round trip EACH (the gather was 4-5 us of the 13.6 us
+    // layer-0 phase of the fused step kernel).  Same entries in the same order, and fmaf(0, w, acc) == acc for the
+    // padding: bit-identical to consume().  The loads are unconditional -- the last iteration re-requests a group it
+    // does not use -- so that the loop body is straight-line code and every wait is an exact count.
+    auto consume_pipelined = [&](int cnt) {
+      auto request = [&](int e0, float *pv, typename VecT<CPL>::T *wv) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pv[e] = my_phi[e0 + e];
+          const unsigned ro = (unsigned)my_k[e0 + e] * (unsigned)H + (unsigned)(CPL * lane);
+          wv[e] = *reinterpret_cast<const typename VecT<CPL>::T *>(a.W0T + (size_t)ro);
+        }
+      };
+      auto multiply = [&](const float *pv, const typename VecT<CPL>::T *wv) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float *f = reinterpret_cast<const float *>(&wv[e]);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[c] = fmaf(pv[e], f[c], acc[c]);
+        }
+      };
+      float pa[8], pb[8];
+      typename VecT<CPL>::T wa[8], wb[8];
+      if (cnt > 0) request(0, pa, wa);
+      for (int e0 = 0; e0 < cnt; e0 += 16) {
+        request(e0 + 8, pb, wb);
+        multiply(pa, wa);
+        request(e0 + 16 < cnt ? e0 + 16 : e0 + 8, pa, wa);
+        multiply(pb, wb);
+      }
+    };
+
     // ---- spatial levels through the per-wave candidate list (fixed knots: three levels at a time,
     // 6 x 6 candidates each; free knots: one level at a time, (2R)^2 candidates in passes of 64)
     constexpr int LSTEP = FREE ? 1 : 3;
@@ -247,10 +281,17 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
         }
         n += a.g.p;
       }
-      const int npad = (n + 7) & ~7;
-      if (lane < npad - n) { my_phi[n + lane] = 0.f; my_k[n + lane] = 0; }
-      __builtin_amdgcn_wave_barrier();
-      consume(npad);
+      if (FREE) {
+        const int npad = (n + 7) & ~7;
+        if (lane < npad - n) { my_phi[n + lane] = 0.f; my_k[n + lane] = 0; }
+        __builtin_amdgcn_wave_barrier();
+        consume(npad);
+      } else {
+        const int npad = (n + 15) & ~15;          // n <= 3 * 36 + 16 = 124, LIST = 144
+        if (lane < npad - n) { my_phi[n + lane] = 0.f; my_k[n + lane] = 0; }
+        __builtin_amdgcn_wave_barrier();
+        consume_pipelined(npad);
+      }
       __builtin_amdgcn_wave_barrier();
     }
 
