@@ -295,12 +295,30 @@ static __device__ __forceinline__ void gemm16_loop_h(f32x4 (*acc)[MAX_NI], const
     }
   }
 }
+// the unrolled ring of gemm16_unrolled for the bf16 operands: K = 64 NCH exactly (256 -> 4 chunks, 128 -> 2)
+template <int MT, int NI, int NCH>
+static __device__ __forceinline__ void gemm16_unrolled_h(f32x4 (*acc)[MAX_NI], const u16 *__restrict__ A,
+                                                         const u16 *__restrict__ Wn, int N, int K, int wave, int c16,
+                                                         int q, const BFragH<MAX_NI> &f0) {
+  BFragH<MAX_NI> f[3];
+  f[0] = f0;
+  if (NCH > 1) load_bfrag_h<NI>(f[1], Wn, N, K, 1, wave, c16, q);
+  if (NCH > 2) load_bfrag_h<NI>(f[2], Wn, N, K, 2, wave, c16, q);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    mma_chunk_h<NI, MT>(acc, f[c % 3], A, c, c16, q);
+    if (c + 3 < NCH) load_bfrag_h<NI>(f[c % 3], Wn, N, K, c + 3, wave, c16, q);
+  }
+}
+
 template <int MT>
 static __device__ __forceinline__ void gemm16_pre_h(f32x4 (*acc)[MAX_NI], const u16 *__restrict__ A,
                                                     const u16 *__restrict__ Wn, int N, int K, int wave, int c16, int q,
                                                     BFragH<MAX_NI> &f0, int rot = 0) {
   if (wave >= (N >> 4)) return;
   if (MAX_NI > 1 && tiles_of(N) > 1) gemm16_loop_h<MT, MAX_NI>(acc, A, Wn, N, K, wave, c16, q, f0, rot);
+  else if (MAX_NI == 1 && rot == 0 && K == 256) gemm16_unrolled_h<MT, 1, 4>(acc, A, Wn, N, K, wave, c16, q, f0);
+  else if (MAX_NI == 1 && rot == 0 && K == 128) gemm16_unrolled_h<MT, 1, 2>(acc, A, Wn, N, K, wave, c16, q, f0);
   else gemm16_loop_h<MT, 1>(acc, A, Wn, N, K, wave, c16, q, f0, rot);
 }
 

@@ -36,7 +36,35 @@ import test_gpu_parity as T
 pytestmark = pytest.mark.gpu
 
 EMU_Y, EMU_LOSS, EMU_GRAD = 5e-3, 5e-4, 1e-2
-Y_TOL, LOSS_TOL, GRAD_TOL = 1e-2, 1e-2, 1e-1
+Y_TOL, LOSS_TOL = 1e-2, 1e-2
+
+# The bf16 configuration's error against the float64 reference, per case and per tensor, as MEASURED on the MI355X with
+# the committed kernels (tests/golden/bf16_achieved.json, written by tools/bf16_error_table.py = this module's
+# measurements dumped).  A test allows 2 x the achieved figure of its own tensor, not a blanket
+# bound: the worst entry is 5.8e-2 (mlp.1.weight of the 227-knot model at 257 rows), most are 3e-3 .. 3e-2.
+ACHIEVED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_achieved.json")
+_MEASURED = {}        # filled by the tests of this run (what tools/bf16_error_table.py dumps)
+
+
+def _achieved():
+    import json
+    if not os.path.exists(ACHIEVED_FILE):
+        return None
+    return json.load(open(ACHIEVED_FILE))
+
+
+def check_against_achieved(case, errs, slack=2.0):
+    """errs: {tensor or 'y' / 'loss': error vs the float64 reference}.  Recorded for the table; asserted against
+    `slack` x the committed achieved figure (a tensor without a figure fails: regenerate the table)."""
+    _MEASURED[case] = {k: float(v) for k, v in errs.items()}
+    table = _achieved()
+    if os.environ.get("STDADK_BF16_TABLE_WRITE"):
+        return
+    assert table is not None, "tests/golden/bf16_achieved.json missing: run tools/bf16_error_table.py on the MI355X box"
+    assert case in table, f"no achieved bf16 errors recorded for {case}: run tools/bf16_error_table.py"
+    for k, e in errs.items():
+        assert k in table[case], (case, k)
+        assert e <= slack * table[case][k] + 1e-12, (case, k, e, table[case][k])
 
 
 def dev():
@@ -175,8 +203,7 @@ def test_bf16_forward_backward_matches_emulation_and_goldens(name, dense):
     for k, e in emu_g.items():
         assert e <= EMU_GRAD, (k, e)
     assert ey <= Y_TOL and el <= LOSS_TOL
-    for k, e in eg.items():
-        assert e <= GRAD_TOL, (k, e)
+    check_against_achieved(f"golden/{name}/{'dense' if dense else 'window'}", dict(eg, y=ey, loss=el))
     # eval mode: same forward without the saved tensors
     m.eval()
     with torch.no_grad():
@@ -219,6 +246,19 @@ def test_bf16_full_batches_match_emulation(B):
         worst = max(worst, e)
         assert e <= EMU_GRAD, (k, e)
     print(f"bf16 full batch B={B}: gradients vs emulation, worst rel-L2 {worst:.1e}")
+    # ... and against the float64 oracle of the reference's arithmetic (no operand rounding): the configuration's own
+    # error at full batch size, per tensor, bounded by 2 x what was measured for it
+    yo, lo, go = orc.train_step_grads(X, coords, t, y, state, cfg)
+    errs = {"loss": abs(loss - lo) / lo}
+    for k, p in m.named_parameters():
+        o, n = by[k]
+        got = eng.grad[o:o + n].cpu().numpy().astype(np.float64)
+        ref = go[k].T if k == "mlp.0.weight" else go[k]
+        errs[k] = T.rel_l2(got, ref.ravel())
+    print(f"bf16 full batch B={B} vs float64 oracle: loss {errs['loss']:.2e}, gradients max "
+          f"{max(v for k, v in errs.items() if k != 'loss'):.2e}")
+    assert errs["loss"] <= LOSS_TOL
+    check_against_achieved(f"full_batch/{B}", errs)
 
 
 # ------------------------------------------------------------------ engine
