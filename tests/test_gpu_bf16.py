@@ -63,6 +63,9 @@ def check_against_achieved(case, errs, slack=2.0):
     assert table is not None, "tests/golden/bf16_achieved.json missing: run tools/bf16_error_table.py on the MI355X box"
     assert case in table, f"no achieved bf16 errors recorded for {case}: run tools/bf16_error_table.py"
     for k, e in errs.items():
+        if k in ("y", "loss"):
+            continue        # recorded for the table; bounded by Y_TOL / LOSS_TOL (a signed sum of roundings: its
+                            # achieved value can be anywhere below the bound, 2 x it means nothing)
         assert k in table[case], (case, k)
         assert e <= slack * table[case][k] + 1e-12, (case, k, e, table[case][k])
 
