@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line:
   cpu_baseline  the oracle's torch-CPU port of the reference's batch body on this box's host cores
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -479,6 +480,8 @@ def main():
                "steps": k4, "gradient_bytes": 4 * e4.flat.numel(), "collectives_ms_per_step": ar4, "scaling": "weak",
                "dtype": args.dtype}
         del e4, m4, c4c, c4t, c4y, perm4
+        gc.collect()
+        torch.cuda.synchronize()
         return res
 
     def c5_sharded_line():
@@ -685,7 +688,13 @@ def main():
                 dt = time.perf_counter() - t1
                 res = {"obs_per_s": b2 * k2 / dt, "ms_per_step": dt / k2 * 1e3,
                        "path": "window" if e2.uses_window else "materialised"}
+                # engines are released HERE, outside any timed region: an engine that ran from a hipGraph holds the
+                # graph's private memory pool, and when Python's cycle collector got round to it in the middle of a LATER
+                # variant's timed loop, that loop stood still for ~70 ms (round 3: the first bf16 line at 16 384 rows read
+                # 12-16 M obs/s instead of 77 M)
                 del e2, m2
+                gc.collect()
+                torch.cuda.synchronize()
                 return res
             # the survey's per-GPU batch sweep: same model, same step, other batch sizes
             out["batch_sweep"] = {str(b2): timed(b2, 40) for b2 in (16384, 65536) if b2 != B and b2 <= n_obs}
