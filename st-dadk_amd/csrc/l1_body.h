@@ -68,9 +68,20 @@ __device__ __forceinline__ void l1_window_fwd_body(const L1FwdArgs &a, float *sm
     bet[c] = LN ? a.beta[CPL * lane + c] : 0.f;
   }
   {
+    // temporal rows of W0^T into LDS: ALL of a thread's pieces requested first, then stored (Kt H 4 B <= 96 KiB =>
+    // at most 6 float4 per thread; clamped, unconditional loads).  As a rolled `dst[i] = src[i]` loop this was
+    // Kt H / 4096 dependent L2 round trips -- five for the 70 temporal knots -- at the head of every workgroup.
     const float4 *src = reinterpret_cast<const float4 *>(a.W0T + (size_t)D0 * H);
     float4 *dst = reinterpret_cast<float4 *>(Wt);
-    for (int i = tid; i < Kt * H / 4; i += FW_T) dst[i] = src[i];
+    const int n4 = Kt * H / 4;
+    if (n4 > 0) {                                   // workgroup-uniform (a model without temporal knots)
+      float4 tmp[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tmp[k] = src[min(tid + FW_T * k, n4 - 1)];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (tid + FW_T * k < n4) dst[tid + FW_T * k] = tmp[k];
+    }
   }
   __syncthreads();
   float *my_phi = lphi + wave * LIST;
@@ -394,9 +405,20 @@ __device__ __forceinline__ void l1_window_fwd_multi_body(const L1FwdArgs &a, flo
   const int D0 = a.g.p + a.g.Ks;
   const int rowf = r0 + R * wave;
   {
+    // temporal rows of W0^T into LDS: ALL of a thread's pieces requested first, then stored (Kt H 4 B <= 96 KiB =>
+    // at most 6 float4 per thread; clamped, unconditional loads).  As a rolled `dst[i] = src[i]` loop this was
+    // Kt H / 4096 dependent L2 round trips -- five for the 70 temporal knots -- at the head of every workgroup.
     const float4 *src = reinterpret_cast<const float4 *>(a.W0T + (size_t)D0 * H);
     float4 *dst = reinterpret_cast<float4 *>(Wt);
-    for (int i = tid; i < Kt * H / 4; i += FW_T) dst[i] = src[i];
+    const int n4 = Kt * H / 4;
+    if (n4 > 0) {                                   // workgroup-uniform (a model without temporal knots)
+      float4 tmp[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tmp[k] = src[min(tid + FW_T * k, n4 - 1)];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (tid + FW_T * k < n4) dst[tid + FW_T * k] = tmp[k];
+    }
   }
   __syncthreads();
   float *my_phi = lphi + wave * LIST * R;

@@ -14,7 +14,7 @@ done
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH=(python3 bench.py --no-cpu-baseline --no-sweep --no-pipeline --clock-warmup-ms 0 --steps 30 --warmup 5 "${ARGS[@]}")
+BENCH=(python3 bench.py --no-cpu-baseline --no-sweep --no-pipeline --clock-warmup-ms 0 --windows 1 --steps 30 --warmup 5 "${ARGS[@]}")
 CMD="rocprofv3 ... -- ${BENCH[*]}"
 echo "== kernel trace + stats"; rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- "${BENCH[@]}" > "$OUT/stats.log" 2>&1 || exit 1
 python tools/prof_summary.py "$OUT/stats" 45 > "$OUT/${TAG}_kernel_stats.md" || exit 1
