@@ -88,7 +88,7 @@ def allreduce_gradients(flat_grad, group=None):
     return flat_grad
 
 
-_RS_NATIVE = {}        # backend name -> does reduce_scatter_tensor work (gloo: not for every build / device)
+_RS_NATIVE = {}        # backend name -> "in_place" | "scratch" (separate output) | "all_reduce" (no reduce-scatter: gloo)
 
 
 def reduce_scatter_gradients(flat_grad, out_slice, group=None):
@@ -101,25 +101,38 @@ def reduce_scatter_gradients(flat_grad, out_slice, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return out_slice
     backend = dist.get_backend(group)
-    if _RS_NATIVE.get(backend, True):
+    mode = _RS_NATIVE.get(backend, "in_place")
+    if mode == "in_place":
+        # RCCL / NCCL reduce-scatter in place: recvbuff = sendbuff + rank * recvcount (what Megatron's distributed
+        # optimiser does with its gradient buffer views)
         try:
             dist.reduce_scatter_tensor(out_slice, flat_grad, op=dist.ReduceOp.SUM, group=group)
-            _RS_NATIVE[backend] = True
+            _RS_NATIVE[backend] = "in_place"
             return out_slice
-        except (RuntimeError, NotImplementedError) as e:
-            if backend == "nccl":
-                raise                      # RCCL has it: a failure there is an error, not a missing feature
-            _RS_NATIVE[backend] = False    # every rank runs the same build: all take this branch together
+        except (RuntimeError, NotImplementedError, ValueError):
+            # refused before anything was enqueued (argument check of this torch build, or a backend without the
+            # collective): every rank runs the same build, so all of them take the next branch together
+            mode = _RS_NATIVE[backend] = "scratch" if backend == "nccl" else "all_reduce"
+    if mode == "scratch":
+        tmp = torch.empty_like(out_slice)
+        dist.reduce_scatter_tensor(tmp, flat_grad, op=dist.ReduceOp.SUM, group=group)
+        out_slice.copy_(tmp)
+        return out_slice
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return out_slice
 
 
 def allgather_parameters(flat, my_slice, group=None):
     """All-gather of the ranks' stepped parameter chunks into the flat buffer (`my_slice` may be this rank's own
-    chunk of `flat`: in place)."""
+    chunk of `flat`: in place, sendbuff = recvbuff + rank * sendcount)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return flat
-    dist.all_gather_into_tensor(flat, my_slice, group=group)
+    try:
+        dist.all_gather_into_tensor(flat, my_slice, group=group)
+    except (RuntimeError, ValueError):
+        if my_slice.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
+            raise
+        dist.all_gather_into_tensor(flat, my_slice.clone(), group=group)      # a build that refuses aliased buffers
     return flat
 
 

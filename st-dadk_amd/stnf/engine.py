@@ -413,6 +413,10 @@ class TrainStep:
             return
         self._enqueue_grads(X, coords, t, y, B, global_rows, idx=idx, ws=ws, prebinned=prebinned)
         if self.shard:
+            if not self.distributed:
+                # world_size=... without a process group is the tests' virtual-rank mode: there the caller plays the
+                # collectives between _enqueue_grads / _shard_sumsq / _shard_adamw itself
+                raise RuntimeError("shard_optimizer=True needs an initialised torch.distributed process group")
             self._enqueue_sharded_optimizer()
             return
         if self.distributed:

@@ -73,7 +73,17 @@ steps(model([1024, 4096, 5184], output_dim=5), 4096, dict(loss="pinball", quanti
 steps(model([25, 81, 121], output_dim=5, use_delta_reparameterization=True), 300,
       dict(loss="pinball", quantile_levels=taus, non_crossing_lambda=0.05))
 steps(model([1024, 4096, 5184]), 4096, dict(sparsity_penalty_type="sparse_group"))
-steps(model([1024, 4096, 5184]), 4096, dict(world_size=2, shard_optimizer=True))
+# sharded optimiser, two virtual ranks driven by hand (the collectives are the caller's in this mode)
+m = model([1024, 4096, 5184], spatial_learnable=True).train()
+eng = TrainStep(m, max_batch=4096, ema_decay=0.99, world_size=2, shard_optimizer=True, domain_penalty_weight=0.01)
+X, c, t, y = data(4096)
+for r in range(2):
+    eng.set_virtual_rank(r)
+    eng._enqueue_grads(None, c[:2048], t[:2048].view(-1), y[:2048], 2048, 4096)
+    eng._shard_sumsq()
+    eng._shard_adamw()
+eng.swap_in_ema(); eng.swap_in_ema()
+calls += 6
 np.random.seed(0)
 site = np.random.rand(20000, 2).astype(np.float32)
 steps(model([1024, 4096], spatial_learnable=True, spatial_init_method="random_site", train_coords=site), 4096,
