@@ -5,6 +5,21 @@
 
 namespace stdadk {
 
+// Slab tiles that a workgroup on ANOTHER XCD reads later in the same launch (FinArgs): every XCD has its own L2,
+// and a device-scope fence (__threadfence) on this part writes back / invalidates the WHOLE L2 -- measured: the
+// merged weight-gradient launch 27 -> 153 us with one fence pair per workgroup.  Relaxed device-scope atomic
+// stores / loads instead carry the scope on the access itself (sc1: written through, read past the non-coherent
+// lines), so the hand-over costs a wait for the stores' acknowledgements and nothing else.
+__device__ __forceinline__ void slab_store(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 slab_load2(const float *p) {      // 8-byte aligned
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
@@ -130,7 +145,7 @@ __device__ __forceinline__ void gemm_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int BM, int BN, bool A_KM, bool B_KM, int VA, int VB>
+template <int BM, int BN, bool A_KM, bool B_KM, int VA, int VB, int DEPTH = 1>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by, int bz, float *lds) {
   constexpr int TM = BM / 64, TN = BN / 64;
   using GA = TileGeom<BM, A_KM>;
@@ -154,19 +169,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float ra[GA::ELEMS], rb[GB::ELEMS];
-  if (kbeg < kend) {
-    load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
-    load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    store_tile<BM, A_KM, VA>(As, ra, m0, g.M, k0, kend);
-    store_tile<BN, B_KM, VB>(Bs, rb, n0, g.N, k0, kend);
-    gemm_lds_barrier();
-    if (k0 + BK < kend) {
-      load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, k0 + BK, kend, ra);
-      load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, k0 + BK, kend, rb);
-    }
+  auto mfma_step = [&]() {
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
       float fa[TM][4], fb[TN][4];
@@ -182,7 +185,50 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
-    gemm_lds_barrier();
+  };
+  if constexpr (DEPTH == 1) {
+    float ra[GA::ELEMS], rb[GB::ELEMS];
+    if (kbeg < kend) {
+      load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+      load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      store_tile<BM, A_KM, VA>(As, ra, m0, g.M, k0, kend);
+      store_tile<BN, B_KM, VB>(Bs, rb, n0, g.N, k0, kend);
+      gemm_lds_barrier();
+      if (k0 + BK < kend) {
+        load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, k0 + BK, kend, ra);
+        load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, k0 + BK, kend, rb);
+      }
+      mfma_step();
+      gemm_lds_barrier();
+    }
+  } else if (kbeg < kend) {
+    // DEPTH K steps of operands in flight (ring of register stages, the step loop unrolled over the ring): a short
+    // K slice is a chain of load -> LDS -> MFMA steps in which one step of matrix work (0.45 us) cannot hide an L2
+    // miss.  The loads are unconditional; a stage beyond the slice re-reads the slice's first step and is never stored.
+    float ra[DEPTH][GA::ELEMS], rb[DEPTH][GB::ELEMS];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int k = kbeg + d * BK, kc = k < kend ? k : kbeg;
+      load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, kc, kend, ra[d]);
+      load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, kc, kend, rb[d]);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += DEPTH * BK) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int k = k0 + d * BK;
+        if (k >= kend) break;
+        store_tile<BM, A_KM, VA>(As, ra[d], m0, g.M, k, kend);
+        store_tile<BN, B_KM, VB>(Bs, rb[d], n0, g.N, k, kend);
+        gemm_lds_barrier();
+        const int kn = k + DEPTH * BK, kc = kn < kend ? kn : kbeg;
+        load_tile<BM, A_KM, VA>(g.A, g.lda, m0, g.M, kc, kend, ra[d]);
+        load_tile<BN, B_KM, VB>(g.B, g.ldb, n0, g.N, kc, kend, rb[d]);
+        mfma_step();
+        gemm_lds_barrier();
+      }
+    }
   }
 
   // epilogue: acc reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile
@@ -206,7 +252,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, int bx, int by
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < g.M) Cbase[(int64_t)row * ldc + col] = acc[i][j][r] + bv;
+        if (row < g.M) {
+          if (g.coherent_slab) slab_store(Cbase + (int64_t)row * ldc + col, acc[i][j][r]);
+          else Cbase[(int64_t)row * ldc + col] = acc[i][j][r] + bv;
+        }
       }
     }
 }
@@ -312,13 +361,181 @@ __device__ __forceinline__ void gemm_tn_tile_body_h(const GemmArgs &g, int bx, i
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < g.M) Cbase[(int64_t)row * g.N + col] = acc[r];
+      if (row < g.M) {
+        if (g.coherent_slab) slab_store(Cbase + (int64_t)row * g.N + col, acc[r]);
+        else Cbase[(int64_t)row * g.N + col] = acc[r];
+      }
     }
   }
 }
 
+// sum of four per-wave values of a 256-thread workgroup through `red` (>= 4 floats of LDS, free to overwrite);
+// the result is valid in thread 0
+__device__ __forceinline__ float block4_sum(float v, float *red) {
+  const float s = wave_sum(v);
+  __syncthreads();                                   // earlier readers of `red`
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+constexpr int REDUCE_TALL_COLS = 16;
+// One workgroup of a table of fixed-order sums dst_j[i] = sum_s src_j[s*stride_j + i] (see reduce_jobs_kernel);
+// returns (every thread) the squares of what this thread wrote.  smem: >= 4 * 64 floats.
+__device__ __forceinline__ float reduce_job_block(const ReduceGroup &grp, int block, float *smem) {
+  int j = 0;
+  while (j + 1 < grp.n && block >= grp.first_block[j + 1]) ++j;
+  const ReduceJob &jb = grp.job[j];
+  const int blk = block - grp.first_block[j];
+  float sq = 0.f;
+  if (jb.wide) {
+    const int c = (blk * 256 + threadIdx.x) * 4;
+    if (c < jb.n) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int s = 0;
+      for (; s + 7 < jb.splits; s += 8) {           // 8 independent loads in flight (same serial order of the adds)
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(jb.src + (int64_t)(s + u) * jb.stride + c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+      for (; s + 3 < jb.splits; s += 4) {           // 4 independent loads in flight
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(jb.src + (int64_t)(s + u) * jb.stride + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+      for (; s < jb.splits; ++s) {
+        const float4 v = *reinterpret_cast<const float4 *>(jb.src + (int64_t)s * jb.stride + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4 *>(jb.dst + c) = acc;
+      sq = (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
+    }
+  } else {
+    // tall job: REDUCE_TALL_COLS columns x 16 groups of partials per workgroup (a thread walks every 16th partial
+    // with 8 independent loads in flight: 256 partials = two round trips; with 64 columns x 4 groups it was eight)
+    float(*red)[REDUCE_TALL_COLS] = reinterpret_cast<float(*)[REDUCE_TALL_COLS]>(smem);
+    constexpr int SG = 256 / REDUCE_TALL_COLS;
+    const int tx = threadIdx.x % REDUCE_TALL_COLS, ty = threadIdx.x / REDUCE_TALL_COLS;
+    const int c = blk * REDUCE_TALL_COLS + tx;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < jb.n) {
+      int s = ty;
+      for (; s + 7 * SG < jb.splits; s += 8 * SG) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = jb.src[(int64_t)(s + SG * u) * jb.stride + c];
+        s0 += (v[0] + v[2]) + (v[4] + v[6]);
+        s1 += (v[1] + v[3]) + (v[5] + v[7]);
+      }
+      for (; s < jb.splits; s += SG) s0 += jb.src[(int64_t)s * jb.stride + c];
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && c < jb.n) {
+      float o = 0.f;
+#pragma unroll
+      for (int q = 0; q < SG; q += 4) o += (red[q][tx] + red[q + 1][tx]) + (red[q + 2][tx] + red[q + 3][tx]);
+      jb.dst[c] = o;
+      sq = o * o;
+    }
+  }
+  return sq;
+}
+
+// Finishing step of one K slice of a grouped job's output tile (FinArgs): once the slice's slab stores
+// (slab_store: device scope) are acknowledged the tile's arrival counter is advanced, and the workgroup that finds
+// the other splits - 1 slices already there sums the tile over the slabs in slice order s = 0, 1, ... (the wide
+// reduce job's order), writes C and the tile's squared-norm slot.
+__device__ __forceinline__ void gemm_tile_finish(const GemmArgs &g, int bx, int by, int *cnt, float *slot, float *lds) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's slab stores have been acknowledged
+  __syncthreads();
+  int *flag = reinterpret_cast<int *>(lds);
+  if (threadIdx.x == 0) flag[0] = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (flag[0] != g.splits - 1) return;                // workgroup-uniform
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // thread -> two neighbouring columns of rows r, r + 8, ..., r + 56 of the tile: a wave's load covers two whole
+  // 256-byte tile rows.  The loads are UNCONDITIONAL from clamped addresses (a load under a branch makes the
+  // compiler wait for it where the paths meet: every one of the splits x 8 loads would pay its full latency --
+  // measured 60 us for this sum), the masks apply to the stores.
+  float sq = 0.f;
+  const int r = threadIdx.x >> 5, c = bx * 64 + 2 * (threadIdx.x & 31);
+  const bool pair_ok = (g.N & 1) == 0 && (g.slab_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(g.slab) & 7) == 0 &&
+                       (reinterpret_cast<uintptr_t>(g.C) & 7) == 0;
+  if (pair_ok) {                                      // workgroup-uniform
+    const bool cok = c < g.N;
+    const int cc = cok ? c : bx * 64;
+#pragma unroll 1
+    for (int hp = 0; hp < 2; ++hp) {                  // rows r + 8 p, p = 4 hp .. 4 hp + 3
+      const float *src[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) src[p] = g.slab + (int64_t)min(by * 64 + 8 * (4 * hp + p) + r, g.M - 1) * g.N + cc;
+      float2 acc[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[p] = make_float2(0.f, 0.f);
+      int s = 0;
+      for (; s + 3 < g.splits; s += 4) {              // 16 independent loads in flight
+        float2 v[4][4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            v[w][p] = slab_load2(src[p] + (int64_t)(s + w) * g.slab_stride);
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) { acc[p].x += v[w][p].x; acc[p].y += v[w][p].y; }
+      }
+      for (; s < g.splits; ++s) {
+        float2 v[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v[p] = slab_load2(src[p] + (int64_t)s * g.slab_stride);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { acc[p].x += v[p].x; acc[p].y += v[p].y; }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = by * 64 + 8 * (4 * hp + p) + r;
+        if (cok && row < g.M) {
+          *reinterpret_cast<float2 *>(g.C + (int64_t)row * g.N + c) = acc[p];
+          sq += acc[p].x * acc[p].x + acc[p].y * acc[p].y;
+        }
+      }
+    }
+  } else {
+    for (int p = 0; p < 8; ++p) {
+      const int row = by * 64 + 8 * p + r;
+      for (int u = 0; u < 2; ++u) {
+        if (row >= g.M || c + u >= g.N) continue;
+        float acc = 0.f;
+        for (int s = 0; s < g.splits; ++s)
+          acc += __hip_atomic_load(g.slab + (int64_t)s * g.slab_stride + (int64_t)row * g.N + c + u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        g.C[(int64_t)row * g.N + c + u] = acc;
+        sq = fmaf(acc, acc, sq);
+      }
+    }
+  }
+  if (slot) {                                         // workgroup-uniform
+    const float t = block4_sum(sq, lds + 8);
+    if (threadIdx.x == 0) slot[0] = t;
+  }
+}
+
+// K steps of operands in flight in the grouped TN tiles (gemm_tile_body's DEPTH).  -DSTDADK_GROUP_DEPTH=3 measured
+// against 1 on one box (round 3): dw_all_kernel 31.0 vs 30.4 us at 4 096 rows, 83.0 vs 80.8 at 16 384, 329-337 vs
+// 317-319 at 65 536 -- the tiles are not waiting for their operands; 1 stays
+#ifndef STDADK_GROUP_DEPTH
+#define STDADK_GROUP_DEPTH 1
+#endif
+constexpr int GROUP_DEPTH = STDADK_GROUP_DEPTH;
 // one workgroup of a grouped TN launch: block -> (job, tile, split) through the prefix table
-__device__ __forceinline__ void gemm_tn_grouped_block(const GemmGroup &grp, int block, float *lds) {
+__device__ __forceinline__ void gemm_tn_grouped_block(const GemmGroup &grp, int block, float *lds,
+                                                      const FinArgs *fin = nullptr) {
   int j = 0;
   while (j + 1 < grp.n && block >= grp.first_block[j + 1]) ++j;
   const GemmArgs &g = grp.job[j];
@@ -341,7 +558,10 @@ __device__ __forceinline__ void gemm_tn_grouped_block(const GemmGroup &grp, int 
     b -= bz * tn * tm;
   }
   if (g.bf16) gemm_tn_tile_body_h(g, b % tn, b / tn, bz, lds);      // workgroup-uniform
-  else gemm_tile_body<64, 64, true, true, 4, 4>(g, b % tn, b / tn, bz, lds);
+  else gemm_tile_body<64, 64, true, true, 4, 4, GROUP_DEPTH>(g, b % tn, b / tn, bz, lds);
+  if (fin && fin->cnt)
+    gemm_tile_finish(g, b % tn, b / tn, fin->cnt + fin->tile0[j] + b, fin->slots ? fin->slots + fin->tile0[j] + b : nullptr,
+                     lds);
 }
 
 }  // namespace stdadk

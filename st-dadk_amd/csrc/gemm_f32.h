@@ -28,6 +28,8 @@ struct GemmArgs {
   int bf16 = 0;         // grouped TN jobs only (STDADK_FLAG_BF16): operands rounded to bf16 as they enter LDS,
                         // v_mfma_f32_32x32x16_bf16, fp32 accumulate
   int xcd_split = 0;    // grouped TN jobs only, set by gemm_tn_grouped_prepare: XCD-aware block order (splits % 8 == 0)
+  int coherent_slab = 0;  // the slab tiles are written with device-scope (write-through) stores: a workgroup on another
+                          // XCD sums them later in the SAME launch (FinArgs), set by launch_dw_all
 };
 
 // a table of TN products for one launch (gemm_tn_grouped_kernel) and of partial-sum reductions
@@ -50,14 +52,32 @@ struct ReduceGroup {
   int n = 0;
   ReduceJob job[REDUCE_GROUP_MAX];
   int first_block[REDUCE_GROUP_MAX + 1];
-  // optional (sq_parts != NULL): partial sums of squares of every value this launch writes, plus of an
-  // already final region sq_src[0..sq_n) — together the squared norm of a whole gradient.
-  // sq_parts[0..256): the region (256 extra workgroups); [256..512): one per reduce workgroup, zero beyond.
+  // optional: partial sums of squares of what this launch writes -- sq_parts[b] for reduce workgroup b (as many
+  // entries as reduce_jobs_block_count() returns) -- and of an already final region sq_src[0..sq_n) --
+  // sq_region_parts[0..256), by 256 extra workgroups; together the squared norm of a whole gradient
   float *sq_parts = nullptr;
+  float *sq_region_parts = nullptr;
   const float *sq_src = nullptr;
   int64_t sq_n = 0;
   int *step_inc = nullptr;       // advanced by one (device step counter), or NULL
   int n_reduce_blocks = 0;       // set by launch_reduce_jobs
+};
+// Finishing work folded into the merged weight-gradient launch (dw_all.hip) instead of a reductions launch behind
+// it: the workgroup that is LAST to deliver its K slice of an output tile (arrival counter per tile) sums the tile's
+// slabs in slice order -- the sum the wide reduce job would have taken -- writes C and leaves the squares of what
+// it wrote in the tile's slot; the column-partial ("tall") reduce jobs ride along as extra workgroups; every knot
+// workgroup leaves the squares of its rows of dW0^T.  The slots replace the squared-norm partials of the
+// reductions launch (the optimiser sums them in slot order: fixed order, no atomics on floats).
+constexpr int FIN_TILES_MAX = 1024;
+struct FinArgs {
+  int *cnt = nullptr;         // [FIN_TILES_MAX] arrival counters, zero when the launch starts (the step's tail kernel
+                              // clears them, TailBwdArgs::zero_ints); NULL = the products' slabs and the tall jobs are
+                              // left to a reductions launch (n_tiles = n_tall = 0), only the knot slots are written
+  float *slots = nullptr;     // squared-norm partials or NULL: [0, n_tiles) output tiles, [n_tiles, n_tiles + n_tall)
+                              // tall reduce workgroups, then one per knot workgroup
+  int tile0[GEMM_GROUP_MAX];  // first counter / slot of every grouped job
+  int n_tiles = 0, n_tall = 0;
+  int *step_inc = nullptr;    // advanced by one (device step counter), or NULL
 };
 int reduce_jobs_block_count(ReduceGroup &grp);    // fills first_block / wide; the launch's reduce workgroups
 int launch_gemm_tn_grouped(GemmGroup &grp, hipStream_t st);     // every job: a_km = b_km = true, aligned

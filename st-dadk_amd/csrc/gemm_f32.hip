@@ -31,17 +31,17 @@ __global__ __launch_bounds__(GT) void gemm_tn_grouped_kernel(GemmGroup grp) {
 }
 
 // dst_j[i] = sum_s src_j[s*stride_j + i], i < n_j, for a table of jobs, fixed summation order.
-//   tall jobs (many partials, few columns: per-workgroup column partials): 64 columns x 4 s-groups
+//   tall jobs (many partials, few columns: per-workgroup column partials): 16 columns x 16 s-groups
 //   wide jobs (few partials, many columns: split-K slabs): one float4 of columns per thread, the
 //              (<= 64) partials summed serially with independent, coalesced loads
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceGroup grp) {
   __shared__ float red[4][64];
   __shared__ float sqred[4];
   const int nrb = grp.n_reduce_blocks;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && grp.step_inc) grp.step_inc[0] += 1;
   if ((int)blockIdx.x >= nrb) {
-    // squared-norm partials of the already final region (sq_parts != NULL only): block b of 256
+    // squared-norm partials of the already final region (sq_region_parts != NULL only): block b of 256
     const int b = (int)blockIdx.x - nrb;
-    if (b == 0 && threadIdx.x == 0 && grp.step_inc) grp.step_inc[0] += 1;
     float acc = 0.f;
     const int64_t stride = 256ll * 256;
     const int64_t i = (int64_t)b * 256 + threadIdx.x;
@@ -56,65 +56,15 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceGroup grp) {
     const float s = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sqred[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      grp.sq_parts[b] = (sqred[0] + sqred[1]) + (sqred[2] + sqred[3]);
-      if (b >= nrb) grp.sq_parts[256 + b] = 0.f;          // slots no reduce workgroup owns
-    }
+    if (threadIdx.x == 0) grp.sq_region_parts[b] = (sqred[0] + sqred[1]) + (sqred[2] + sqred[3]);
     return;
   }
-  int j = 0;
-  while (j + 1 < grp.n && (int)blockIdx.x >= grp.first_block[j + 1]) ++j;
-  const ReduceJob &jb = grp.job[j];
-  const int blk = blockIdx.x - grp.first_block[j];
-  float sq = 0.f;                 // squares of what this thread writes
-  if (jb.wide) {
-    const int c = (blk * 256 + threadIdx.x) * 4;
-    if (c < jb.n) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      int s = 0;
-      for (; s + 3 < jb.splits; s += 4) {           // 4 independent loads in flight
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(jb.src + (int64_t)(s + u) * jb.stride + c);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-      }
-      for (; s < jb.splits; ++s) {
-        const float4 v = *reinterpret_cast<const float4 *>(jb.src + (int64_t)s * jb.stride + c);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      }
-      *reinterpret_cast<float4 *>(jb.dst + c) = acc;
-      sq = (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
-    }
-  } else {
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blk * 64 + tx;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < jb.n) {
-      // 8 independent loads per pass (a loop of one load + add would wait on every load)
-      int s = ty;
-      for (; s + 28 < jb.splits; s += 32) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = jb.src[(int64_t)(s + 4 * u) * jb.stride + c];
-        s0 += (v[0] + v[2]) + (v[4] + v[6]);
-        s1 += (v[1] + v[3]) + (v[5] + v[7]);
-      }
-      for (; s < jb.splits; s += 4) s0 += jb.src[(int64_t)s * jb.stride + c];
-    }
-    red[ty][tx] = s0 + s1;
-    __syncthreads();
-    if (ty == 0 && c < jb.n) {
-      const float o = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-      jb.dst[c] = o;
-      sq = o * o;
-    }
-  }
+  const float sq = reduce_job_block(grp, (int)blockIdx.x, &red[0][0]);   // squares of what this thread wrote
   if (grp.sq_parts) {              // workgroup-uniform
     const float s = wave_sum(sq);
     if ((threadIdx.x & 63) == 0) sqred[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) grp.sq_parts[256 + blockIdx.x] = (sqred[0] + sqred[1]) + (sqred[2] + sqred[3]);
+    if (threadIdx.x == 0) grp.sq_parts[blockIdx.x] = (sqred[0] + sqred[1]) + (sqred[2] + sqred[3]);
   }
 }
 
@@ -154,7 +104,7 @@ int reduce_jobs_block_count(ReduceGroup &grp) {
     jb.wide = jb.splits <= 64 && jb.n % 4 == 0 && jb.stride % 4 == 0 &&
               ((reinterpret_cast<uintptr_t>(jb.src) | reinterpret_cast<uintptr_t>(jb.dst)) & 15) == 0;
     grp.first_block[j] = nb;
-    nb += (int)ceil_div(jb.n, jb.wide ? 1024 : 64);
+    nb += (int)ceil_div(jb.n, jb.wide ? 1024 : REDUCE_TALL_COLS);
   }
   grp.n_reduce_blocks = nb;
   return nb;
@@ -162,9 +112,10 @@ int reduce_jobs_block_count(ReduceGroup &grp) {
 
 int launch_reduce_jobs(ReduceGroup &grp, hipStream_t st) {
   int nb = reduce_jobs_block_count(grp);
-  if (grp.sq_parts) {
-    STDADK_REQUIRE(nb <= 256 && grp.sq_src && (reinterpret_cast<uintptr_t>(grp.sq_src) & 15) == 0, STDADK_E_ARG,
-                   "reduce_jobs: squared-norm partials need <= 256 reduce workgroups (%d) and an aligned region", nb);
+  STDADK_REQUIRE(!grp.step_inc || nb > 0, STDADK_E_ARG, "reduce_jobs: the step counter rides on the first reduce workgroup");
+  if (grp.sq_region_parts) {
+    STDADK_REQUIRE(grp.sq_src && (reinterpret_cast<uintptr_t>(grp.sq_src) & 15) == 0, STDADK_E_ARG,
+                   "reduce_jobs: squared-norm partials of a region need an aligned region");
     nb += 256;
   }
   if (nb == 0) return 0;

@@ -24,8 +24,9 @@ __device__ __forceinline__ float basis_prime_cs(float r) {
 // KNOTS (learnable knots): the wave also accumulates sum_b q_b dZ[b,:] for q = the three per-pair
 // factors of d cx, d cy, d log_bw; one dot product with its W0^T row at the end turns them into the
 // knot's gradient — sum_b (dZ[b,:] . W0^T[k,:]) q_b without a reduction per pair.
+// Returns this lane's share of the squares of the row of dW0^T its wave wrote (0 for a wave without a knot).
 template <int CPL, int BASIS, bool KNOTS>
-__device__ __forceinline__ void l1_window_bwd_body(const L1BwdArgs &a, const int block) {
+__device__ __forceinline__ float l1_window_bwd_body(const L1BwdArgs &a, const int block) {
   constexpr int H = 64 * CPL;
   constexpr int NQ = KNOTS ? 3 : 0;
   __shared__ float lphi[BW_T / 64][BW_LIST + 8];
@@ -45,11 +46,11 @@ __device__ __forceinline__ void l1_window_bwd_body(const L1BwdArgs &a, const int
       if (q < np) break;
       q -= np;
     }
-    if (l >= a.g.n_levels) return;
+    if (l >= a.g.n_levels) return 0.f;
     k = a.g.off[l] + r0 * a.g.side[l] + q;            // q = (ix - r0) * side + iy
   } else {
     k = block * (BW_T / 64) + wave;                   // knots in table order: level 0 (coarsest) first
-    if (k >= a.g.Ks) return;
+    if (k >= a.g.Ks) return 0.f;
   }
   float *my_phi = lphi[wave];
   int *my_idx = lidx[wave];
@@ -202,6 +203,10 @@ __device__ __forceinline__ void l1_window_bwd_body(const L1BwdArgs &a, const int
 #pragma unroll
   for (int c = 0; c < CPL; ++c) f[c] = acc[c];
   *reinterpret_cast<typename VecT<CPL>::T *>(a.dW0T + (size_t)(a.g.p + k) * H + CPL * lane) = o;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) sq = fmaf(acc[c], acc[c], sq);
+  return sq;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -212,8 +217,9 @@ __device__ __forceinline__ void l1_window_bwd_body(const L1BwdArgs &a, const int
 // so the rows of dW0^T are bit-identical to the one-knot-per-wave body.  Groups: level by level, ceil(side / 2)
 // pairs per grid row (NK = 2) or ceil(side / 2)^2 blocks of 2 x 2 (NK = 4); knots past the edge of an odd grid
 // are absent.  knot_group_count() in window.hip counts the groups for the launch.
+// Returns this lane's share of the squares of the rows its wave wrote, as l1_window_bwd_body.
 template <int CPL, int BASIS, int NK>
-__device__ __forceinline__ void l1_window_bwd_multi_body(const L1BwdArgs &a, const int block) {
+__device__ __forceinline__ float l1_window_bwd_multi_body(const L1BwdArgs &a, const int block) {
   constexpr int H = 64 * CPL;
   constexpr int NX = NK / 2;                          // knots along ix
   __shared__ float lphi[BW_T / 64][NK][BW_LIST + 8];
@@ -235,7 +241,7 @@ __device__ __forceinline__ void l1_window_bwd_multi_body(const L1BwdArgs &a, con
       if (q < np) break;
       q -= np;
     }
-    if (l >= a.g.n_levels) return;
+    if (l >= a.g.n_levels) return 0.f;
     const int hp = (a.g.side[l] + 1) >> 1;
     const int gx = q / hp;
     ix = r0 + gx; iy = 2 * (q - gx * hp);
@@ -247,7 +253,7 @@ __device__ __forceinline__ void l1_window_bwd_multi_body(const L1BwdArgs &a, con
       if (q < np) break;
       q -= np;
     }
-    if (l >= a.g.n_levels) return;
+    if (l >= a.g.n_levels) return 0.f;
     const int hp = (a.g.side[l] + 1) >> 1;
     const int gx = q / hp;
     ix = NX * gx; iy = 2 * (q - gx * hp);
@@ -383,16 +389,18 @@ __device__ __forceinline__ void l1_window_bwd_multi_body(const L1BwdArgs &a, con
   __builtin_amdgcn_wave_barrier();
   flush(npad);
 
+  float sq = 0.f;
 #pragma unroll
   for (int j = 0; j < NK; ++j) {
     if (has[j]) {
       typename VecT<CPL>::T o;
       float *fo = reinterpret_cast<float *>(&o);
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) fo[c] = acc[j][c];
+      for (int c = 0; c < CPL; ++c) { fo[c] = acc[j][c]; sq = fmaf(acc[j][c], acc[j][c], sq); }
       *reinterpret_cast<typename VecT<CPL>::T *>(a.dW0T + (size_t)(a.g.p + kk[j]) * H + CPL * lane) = o;
     }
   }
+  return sq;
 }
 
 }  // namespace stdadk

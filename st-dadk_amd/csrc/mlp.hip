@@ -33,6 +33,10 @@ static int bwd_rows(int64_t B) {
 // ---------------------------------------------------------------------------------------------
 enum PlanMode { PLAN_MLP = 0, PLAN_STEP_DENSE = 1, PLAN_STEP_WINDOW = 2 };
 
+// rows from which the merged weight-gradient launch also does the reductions (run_backward, FinArgs): measured
+// per step at 8 192 / 16 384 / 32 768 / 65 536 rows: +4 / 0 / -9 / -17 us against the reductions launch
+constexpr int64_t FIN_FULL_MIN_ROWS = 49152;
+
 struct Plan {
   int L;
   int64_t B;
@@ -50,11 +54,13 @@ struct Plan {
   size_t ypred, dY;                    // [B*Q]
   size_t keys, hist, cursor, cell_start, perm_tmp, perm, xs, ys, ts, y_s, X_s;
   int G;
+  size_t fin_cnt, fin_slots; int fin_cap;   // window path: arrival counters / squared-norm slots of the merged dW launch
   size_t total_floats;
 };
 
 static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = PLAN_MLP, int p_cov = 0,
-                      int Kt = 0, int64_t Ks_learn = 0, int64_t Ks_scattered = 0, int n_levels = 0) {
+                      int Kt = 0, int64_t Ks_learn = 0, int64_t Ks_scattered = 0, int n_levels = 0,
+                      int64_t Ks_window = 0) {
   p->L = d->n_hidden;
   p->B = B;
   size_t off = 0;
@@ -163,6 +169,14 @@ static void make_plan(const stdadk_mlp_desc *d, int64_t B, Plan *p, int mode = P
     p->xs = take(B); p->ys = take(B); p->ts = take(B);
     p->y_s = take((size_t)B * d->out_dim);
     p->X_s = take((size_t)B * (p_cov > 0 ? p_cov : 1));
+  }
+  p->fin_cnt = p->fin_slots = 0; p->fin_cap = 0;
+  if (mode == PLAN_STEP_WINDOW) {
+    // output tiles + tall reduce workgroups + knot workgroups (at most one per knot + the padding of the
+    // XCD-striped order), see FinArgs
+    p->fin_cap = FIN_TILES_MAX + 1024 + (int)Ks_window + 64;
+    p->fin_cnt = take(FIN_TILES_MAX);
+    p->fin_slots = take((size_t)p->fin_cap);
   }
   p->total_floats = off;
 }
@@ -506,7 +520,11 @@ struct Ctx {
   float *gradsq = nullptr;      // [STDADK_GRADSQ_PARTS] or NULL
   int *step_inc = nullptr;
   bool gradsq_done = false, all_grouped = true;
+  const float *gradsq_out = nullptr;   // where the partials went when gradsq_done (gradsq, or the slots of the merged
+  int gradsq_n = 0;                    // dW launch) and how many
   bool merge_dw = false, dw_pend = false;   // window path: grouped dW products + per-knot gather as one launch
+  int fin = 0;                  // ... 2: which also does the reductions (FinArgs; the tail launch cleared the counters);
+                                // 1: which leaves the squared-norm slots of its knot rows, reductions launch behind it
   GemmGroup gg_pend;
   ReduceGroup rg_pend;
   bool l1_pend_valid = false;   // window path, B <= 4096: the layer-0 launch is parked as well
@@ -731,6 +749,24 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     a.act_last = ws + pl.act[L - 1]; a.part_head = part;
     a.layernorm = d->layernorm; a.drop_p = c.dp; a.seed = c.seed; a.step_dev = c.step_dev;
     a.bf16 = c.bf16 ? 1 : 0;
+    // merged weight-gradient launch: with the reductions inside it (FinArgs; this tail launch clears the arrival
+    // counters) for large batches, where the K slices of a tile arrive spread out and the sums hide under the rest
+    // of the launch; below that the last slices arrive together at the end of the launch and their sums would
+    // extend it by more than the reductions launch costs (measured at 4 096 rows: 45 us against 27.6 + 7.7), so the
+    // launch only leaves the squared norms of its knot rows.  Environment STDADK_DW_FIN=0|1|2 forces a mode
+    // (0 = the round-2 path: reductions launch that also re-reads the knot rows for their norm).
+    c.fin = 0;
+    if (c.merge_dw && !layer0_dense && pl.fin_cap > 0) {
+      int64_t tiles = 0;
+      for (int l = 1; l < L; ++l) tiles += ceil_div(d->hidden[l], 64) * ceil_div(d->hidden[l - 1], 64);
+      for (int e = 0; e < c.n_extra; ++e) tiles += ceil_div(c.extra[e].M, 64) * ceil_div(d->hidden[0], 64);
+      const char *e = getenv("STDADK_DW_FIN");
+      c.fin = e ? atoi(e) : (B >= FIN_FULL_MIN_ROWS ? 2 : 1);
+      if (c.fin < 0 || c.fin > 2) c.fin = 1;
+      if (c.fin == 2 && tiles > FIN_TILES_MAX) c.fin = 1;
+    }
+    a.zero_ints = c.fin == 2 ? reinterpret_cast<int *>(ws + pl.fin_cnt) : nullptr;
+    a.n_zero = c.fin == 2 ? FIN_TILES_MAX : 0;
     { const char *e = getenv("STDADK_TAIL_BWD_STAMPS"); a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     if (c.pend_valid) {
       c.pend_valid = false;
@@ -771,7 +807,7 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
         g.splits = gemm_pick_splits(M, N, (int)B, &g.kps, false);
         g.slab = slab + slab_off; g.slab_stride = (int64_t)M * N;
         slab_off += (size_t)g.splits * M * N;
-        add_reduce(g.slab, C, M * N, g.splits, g.slab_stride);
+        if (c.fin != 2) add_reduce(g.slab, C, M * N, g.splits, g.slab_stride);   // 2: the last K slice to arrive sums
         return 0;
       }
       c.all_grouped = false;
@@ -819,11 +855,12 @@ static int run_backward(Ctx &c, const float *dY, const float *features, int64_t 
     }
     rc = launch_gemm_tn_grouped(gg, st);
     if (rc) return rc;
-    if (c.gradsq && c.all_grouped && layer0_dense && dw0_in_group && reduce_jobs_block_count(rg) <= 256) {
+    if (c.gradsq && c.all_grouped && layer0_dense && dw0_in_group && reduce_jobs_block_count(rg) > 0 &&
+        reduce_jobs_block_count(rg) <= STDADK_GRADSQ_PARTS) {
       // one-call step: every gradient of the step is an output of this reductions launch, which then also
-      // leaves the squared-norm partials for the clip (no region beside them: sq_n = 0)
-      rg.sq_parts = c.gradsq; rg.sq_src = G->W[0]; rg.sq_n = 0; rg.step_inc = c.step_inc;
-      c.gradsq_done = true;
+      // leaves the squared-norm partials for the clip (no region beside them)
+      rg.sq_parts = c.gradsq; rg.step_inc = c.step_inc;
+      c.gradsq_done = true; c.gradsq_out = c.gradsq; c.gradsq_n = reduce_jobs_block_count(rg);
     }
     rc = launch_reduce_jobs(rg, st);
     if (rc) return rc;
@@ -1136,7 +1173,7 @@ extern "C" size_t stdadk_step_workspace_bytes(const stdadk_basis_desc *b, const 
   if (check_desc(d) != 0 || check_basis(b, d) != 0 || B < 0 || B >= (1ll << 31)) return 0;
   Plan p;
   make_plan(d, B > 0 ? B : 1, &p, want_window(b, d, flags) ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt,
-            learn_ks(b, flags), is_scattered(b, flags) ? b->Ks : 0, b->n_levels);
+            learn_ks(b, flags), is_scattered(b, flags) ? b->Ks : 0, b->n_levels, b->Ks);
   return p.total_floats * sizeof(float);
 }
 
@@ -1153,7 +1190,7 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
   if (rc) return rc;
   c.scattered = *window && is_scattered(b, flags);
   make_plan(d, B, &c.pl, *window ? PLAN_STEP_WINDOW : PLAN_STEP_DENSE, b->p, (int)b->Kt, learn_ks(b, flags),
-            c.scattered ? b->Ks : 0, b->n_levels);
+            c.scattered ? b->Ks : 0, b->n_levels, b->Ks);
   c.log_bw = (flags & STDADK_FLAG_LOG_BW) != 0;
   c.bf16 = (flags & STDADK_FLAG_BF16) != 0;
   STDADK_REQUIRE(!c.bf16 || (tail_enabled() && d->n_hidden >= 1 && tail_supported(d, 1)), STDADK_E_ARG,
@@ -1172,7 +1209,8 @@ static int step_common(Ctx &c, const stdadk_basis_desc *b, const stdadk_mlp_desc
 }
 
 // dW0^T spatial rows (window path): every knot row by the wave that owns it
-static int window_dw0(Ctx &c, hipStream_t st, GemmGroup *with_products = nullptr) {
+static int window_dw0(Ctx &c, hipStream_t st, GemmGroup *with_products = nullptr, const FinArgs *fin = nullptr,
+                      ReduceGroup *tall = nullptr, int *n_slots = nullptr, int slot_cap = 0) {
   const stdadk_basis_desc *b = c.basis;
   float *ws = c.ws;
   L1BwdArgs a;
@@ -1186,6 +1224,18 @@ static int window_dw0(Ctx &c, hipStream_t st, GemmGroup *with_products = nullptr
     a.g.bw = ws + c.pl.bw_exp;
     a.W0T = c.P->W[0];
     a.kpart = ws + c.pl.kpart;
+  }
+  if (with_products && fin) {
+    int need = dw_all_knot_blocks(a);
+    if (fin->cnt) {
+      STDADK_REQUIRE(tall && tall->n > 0, STDADK_E_ARG, "dw_all: finishing work without its reduce table");
+      for (int j = 0; j < with_products->n; ++j)
+        need += (int)(ceil_div(with_products->job[j].M, 64) * ceil_div(with_products->job[j].N, 64));
+      need += reduce_jobs_block_count(*tall);
+    }
+    STDADK_REQUIRE(need <= slot_cap, STDADK_E_WORKSPACE, "dw_all: %d squared-norm slots, the plan holds %d", need,
+                   slot_cap);
+    return launch_dw_all(*with_products, a, b->basis, st, fin, tall, n_slots);
   }
   if (with_products) return launch_dw_all(*with_products, a, b->basis, st);
   return l1_window_backward(a, b->basis, st);
@@ -1275,16 +1325,46 @@ static int step_backward(Ctx &c, const stdadk_basis_desc *b, bool window, const 
   if (rc) return rc;
   if (c.dw_pend) {
     c.dw_pend = false;
+    const bool sq = c.gradsq && c.all_grouped;
+    const int fin_mode = c.fin;
+    c.fin = 0;
+    if (fin_mode == 2) {
+      // products, per-knot gather, every fixed-order sum and the squared-norm partials: ONE launch
+      FinArgs fin;
+      fin.cnt = reinterpret_cast<int *>(ws + c.pl.fin_cnt);
+      fin.slots = sq ? ws + c.pl.fin_slots : nullptr;
+      fin.step_inc = sq ? c.step_inc : nullptr;
+      int n_slots = 0;
+      rc = window_dw0(c, c.st, &c.gg_pend, &fin, &c.rg_pend, &n_slots, c.pl.fin_cap);
+      if (rc) return rc;
+      if (sq) { c.gradsq_done = true; c.gradsq_out = fin.slots; c.gradsq_n = n_slots; }
+      return 0;
+    }
+    const int nrb = reduce_jobs_block_count(c.rg_pend);
+    if (fin_mode == 1 && sq && nrb > 0) {
+      // the knot workgroups leave the squares of the rows they write (no second pass over dW0^T), the reductions
+      // launch adds the partials of what it writes behind them
+      FinArgs fin;
+      fin.slots = ws + c.pl.fin_slots;
+      int n_knot = 0;
+      rc = window_dw0(c, c.st, &c.gg_pend, &fin, nullptr, &n_knot, c.pl.fin_cap - nrb);
+      if (rc) return rc;
+      c.rg_pend.sq_parts = fin.slots + n_knot;
+      c.rg_pend.step_inc = c.step_inc;
+      c.gradsq_done = true; c.gradsq_out = fin.slots; c.gradsq_n = n_knot + nrb;
+      return launch_reduce_jobs(c.rg_pend, c.st);
+    }
     rc = window_dw0(c, c.st, &c.gg_pend);
     if (rc) return rc;
-    if (c.gradsq && c.all_grouped && reduce_jobs_block_count(c.rg_pend) <= 256) {
+    if (sq && nrb > 0 && nrb <= STDADK_GRADSQ_PARTS - 256) {
       // every gradient of the step is either an output of this launch or a spatial row of dW0^T (final
       // after the launch above): their squared norm comes out of the same launch
-      c.rg_pend.sq_parts = c.gradsq;
+      c.rg_pend.sq_region_parts = c.gradsq;
+      c.rg_pend.sq_parts = c.gradsq + 256;
       c.rg_pend.sq_src = c.G->W[0] + (size_t)b->p * H;
       c.rg_pend.sq_n = (int64_t)b->Ks * H;
       c.rg_pend.step_inc = c.step_inc;
-      c.gradsq_done = true;
+      c.gradsq_done = true; c.gradsq_out = c.gradsq; c.gradsq_n = 256 + nrb;
     }
     return launch_reduce_jobs(c.rg_pend, c.st);
   }
@@ -1509,11 +1589,14 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
                               uint64_t drop_seed, const int32_t *step_dev, int32_t flags,
                               stdadk_stream_t stream, stdadk_stream_t aux_stream,
                               float *gradsq_parts = nullptr, int32_t *step_inc = nullptr,
-                              bool *gradsq_done = nullptr) {
+                              const float **gradsq_out = nullptr, int *gradsq_n = nullptr) {
   if (B == 0) return 0;
   Ctx c;
   c.gradsq = gradsq_parts; c.step_inc = step_inc;
-  struct Done { Ctx &c; bool *out; ~Done() { if (out) *out = c.gradsq_done; } } done_guard{c, gradsq_done};
+  struct Done {
+    Ctx &c; const float **out; int *n;
+    ~Done() { if (out) { *out = c.gradsq_done ? c.gradsq_out : nullptr; *n = c.gradsq_done ? c.gradsq_n : 0; } }
+  } done_guard{c, gradsq_out, gradsq_n};
   bool window;
   int rc = step_common(c, b, d, B, workspace, workspace_bytes, flags, &window);
   if (rc) return rc;
@@ -1577,12 +1660,13 @@ extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_ml
   if (B == 0) return 0;
   const bool clip = o->max_norm > 0.f;
   const bool sparse = sparsity && sparsity->kind != STDADK_SPARSITY_NONE;
-  bool sq_done = false;
+  const float *sq_parts = nullptr;   // where the step's own launches left the squared-norm partials, if they did
+  int sq_n = 0;
   // with a sparsity penalty the gradient changes once more after the reductions: the norm is a pass of its own
   const bool fuse_sq = clip && !sparse;
   int rc = train_fwd_bwd_impl(b, d, P, G, coords, t, X, y, idx, B, grad_scale, loss, loss_sum, nullptr, workspace,
                               workspace_bytes, drop_seed, o->step_dev, flags, stream, nullptr,
-                              fuse_sq ? o->sumsq_parts : nullptr, fuse_sq ? o->step_dev : nullptr, &sq_done);
+                              fuse_sq ? o->sumsq_parts : nullptr, fuse_sq ? o->step_dev : nullptr, &sq_parts, &sq_n);
   if (rc) return rc;
   if (sparse) {
     const bool w0_t = (flags & STDADK_FLAG_W0_T) != 0;
@@ -1592,8 +1676,9 @@ extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_ml
     if (rc) return rc;
   }
   int n_parts = 0;
-  if (clip && sq_done) {
-    n_parts = STDADK_GRADSQ_PARTS;                 // partials (and the step advance) came out of the reductions launch
+  const float *parts = o->sumsq_parts;
+  if (clip && sq_parts) {
+    parts = sq_parts; n_parts = sq_n;              // partials (and the step advance) came out of the step's launches
   } else if (clip) {
     rc = stdadk_sumsq_f32(o->g, o->n, o->sumsq_parts, o->step_dev, stream);
     if (rc) return rc;
@@ -1603,7 +1688,7 @@ extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_ml
     if (rc) return rc;
   }
   return stdadk_adamw_ema_f32(o->p, o->g, o->m, o->v, o->ema, o->n, o->lr, o->lr_dev, o->beta1, o->beta2, o->eps,
-                              o->weight_decay, 1, o->step_dev, o->max_norm, clip ? o->sumsq_parts : nullptr, n_parts,
+                              o->weight_decay, 1, o->step_dev, o->max_norm, clip ? parts : nullptr, n_parts,
                               1.0f, o->ema_decay, o->shadow, o->nonfinite_step ? loss_sum : nullptr, o->nonfinite_step,
                               stream);
 }

@@ -93,6 +93,8 @@ struct TailBwdArgs {
   const int *step_dev;
   int bf16;                     // STDADK_FLAG_BF16: dA = dZ W with bf16 operands (L[i].WTbf)
   int krot;                     // as in TailFwdArgs
+  int *zero_ints = nullptr;     // n_zero ints the workgroup of tile 0 clears (arrival counters of the weight-gradient
+  int n_zero = 0;               // launch behind this one, FinArgs), or NULL
   unsigned long long *stamps;   // -DSTDADK_DIAG builds only (see TailFwdArgs), else NULL
 };
 

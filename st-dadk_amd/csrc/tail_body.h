@@ -930,6 +930,8 @@ static __device__ __forceinline__ void tail_bwd_body(const TailBwdArgs &a, float
   const int row0 = tile * R;
   const int rot = a.krot ? (int)(blockIdx.x >> 3) : 0;          // as in the forward body
   STAMP(0);
+  if (tile == 0 && a.zero_ints)
+    for (int i = tid; i < a.n_zero; i += (int)blockDim.x) a.zero_ints[i] = 0;
   // Global inputs of a layer's LayerNorm-backward phase: all loads issued together from clamped
   // addresses, unconditionally (one L2 round trip), and one phase EARLY — for the last layer right here
   // (hidden behind the head phase),

@@ -121,7 +121,11 @@ int l1_window_backward(L1BwdArgs a, int basis, hipStream_t st);
 #include "gemm_f32.h"
 namespace stdadk {
 // the grouped dW products of the other layers and this per-knot gather as ONE launch (dw_all.hip)
-int launch_dw_all(GemmGroup &grp, const L1BwdArgs &a, int basis, hipStream_t st);
+// fin (optional, fin->cnt != NULL): the launch also finishes the products (FinArgs: last-arriving K slice sums its
+// tile), runs the tall reduce jobs of `tall` and leaves squared-norm slots; *n_slots = how many slots it writes
+int launch_dw_all(GemmGroup &grp, const L1BwdArgs &a, int basis, hipStream_t st, const FinArgs *fin = nullptr,
+                  ReduceGroup *tall = nullptr, int *n_slots = nullptr);
+int dw_all_knot_blocks(const L1BwdArgs &a);      // knot workgroups of the launch (for sizing the slots)
 
 // out[perm[i]*Q + q] = in[i*Q + q]
 int unpermute_rows(const float *in, const int *perm, int B, int Q, float *out, hipStream_t st);

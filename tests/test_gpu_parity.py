@@ -641,8 +641,10 @@ def test_engine_two_streams_equals_one():
         res.append((eng.mean_loss(), eng.flat.clone()))
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])   # the loss is summed with float atomics
     # Same kernels and the same order of every gradient sum; only the clip norm differs in its last bits
-    # (one stream: partials out of the reductions launch, 512 of them; two streams: stdadk_sumsq_f32, 256).
-    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=3e-7)
+    # (one stream: partials out of the weight-gradient and reductions launches, one per workgroup; two streams:
+    # stdadk_sumsq_f32, 256).  Adam (eps 1e-8) turns that into up to 1e-6 on a handful of near-zero entries after
+    # three steps.
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("name,dense,clip", [("c2_b257", False, 1.0), ("c2_b257", False, 0.0),
@@ -677,9 +679,11 @@ def test_one_call_step_equals_split_calls(name, dense, clip):
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
     if clip == 0.0:
         assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
-    else:   # the squared norm is summed in a different order
-        torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=3e-7)
-        torch.testing.assert_close(res[0][2], res[1][2], rtol=2e-6, atol=3e-7)
+    else:   # the squared norm is summed in a different order (per-workgroup partials of the step's own launches
+        # against stdadk_sumsq_f32's 256); at lr 1e-2 Adam (eps 1e-8) turns that into up to 1e-6 on a handful of
+        # near-zero gradient entries after three steps
+        torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-6, atol=2e-6)
+        torch.testing.assert_close(res[0][2], res[1][2], rtol=2e-6, atol=2e-6)
 
 
 def test_reference_style_loop_matches_engine():

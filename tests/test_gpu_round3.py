@@ -394,3 +394,60 @@ torch.save(eng.grad.cpu(), sys.argv[1])
     a, b = outs
     assert not torch.equal(a, b)                         # the order did change
     assert float((a - b).norm() / b.norm()) <= 2e-6
+
+
+# ------------------------------------------------------------------ reductions folded into the merged dW launch
+def _fin_run(cfg, monkeypatch, mode, dtype="f32", steps=3, dropout=0.0):
+    """Gradients of one batch (data-parallel entry: forward + backward only) and the parameters after `steps` whole
+    steps, with STDADK_DW_FIN=mode: 2 = the reductions inside dw_all_kernel, 1 = dw_all_kernel leaves the squared
+    norms of its knot rows and reduce_jobs_kernel does the sums, 0 = reduce_jobs_kernel also re-reads the knot rows."""
+    from stnf.engine import TrainStep
+    monkeypatch.setenv("STDADK_DW_FIN", str(mode))
+    d = dev()
+    B = cfg["B"]
+    X, coords, t, y = (torch.from_numpy(a).to(d) if a is not None else None for a in cases.make_inputs(cfg))
+    if cfg["p"] == 0:
+        X = None
+    # eps in Adam's linear regime (as test_gpu_round2._DP_EPS): the two routes sum the clip norm over different
+    # partials, and with eps 1e-8 Adam turns rounding-level differences of near-zero gradient entries into O(lr) steps
+    kw = dict(lr=1e-3, grad_clip=0.5, max_batch=B, dtype=dtype, eps=R2._DP_EPS)
+    m = T.build_model(cfg, dropout=dropout).train()
+    g_eng = TrainStep(m, world_size=2, sync_init=False, **kw)
+    g_eng._enqueue_grads(X, coords, t.view(-1), y, B, B)
+    torch.cuda.synchronize()
+    grad = g_eng.grad.clone()
+    m2 = T.build_model(cfg, dropout=dropout).train()
+    eng = TrainStep(m2, **kw)
+    losses = []
+    for _ in range(steps):
+        eng.step(X, coords, t.view(-1), y)
+        losses.append(eng.mean_loss())
+    torch.cuda.synchronize()
+    return grad, eng.flat.clone(), losses, int(eng.step_dev.item())
+
+
+@pytest.mark.parametrize("name,B,dtype", [("c2_b257", 4096, "f32"), ("c2_b257", 300, "f32"), ("default227", 227, "f32"),
+                                           ("c2_b257", 20000, "f32"), ("c2_b257", 4096, "bf16"),
+                                           ("c2_b257_noln", 1000, "f32"), ("default227_tri", 4096, "f32")])
+def test_reductions_inside_the_weight_gradient_launch(name, B, dtype, monkeypatch):
+    """dw_all_kernel with the finishing work (last-arriving K slice sums its tile's slabs in slice order, tall reduce
+    jobs as extra workgroups, squared-norm slots; the default from 24 576 rows) and dw_all_kernel leaving only the
+    squared norms of its knot rows (the default below that) against the round-2 route (reduce_jobs_kernel behind it,
+    which re-reads the knot rows): the gradients are the same sums in the same order (bit-identical while a product
+    has <= 64 K slices, which is the wide reduce job's serial order); the clip norm is summed over other partials, so
+    whole steps agree to rounding."""
+    if any(os.environ.get(k) for k in ("STDADK_NO_DW_ALL", "STDADK_NO_FUSED_TAIL")):
+        pytest.skip("the merged weight-gradient launch is switched off")
+    cfg = dict(cases.MODEL_CASES[name], B=B, seed=11)
+    g0, p0, l0, s0 = _fin_run(cfg, monkeypatch, 0, dtype=dtype)
+    for mode in (1, 2):
+        g1, p1, l1, s1 = _fin_run(cfg, monkeypatch, mode, dtype=dtype)
+        assert s1 == s0 == 3
+        assert torch.isfinite(g1).all() and float(g1.norm()) > 0
+        if B <= 4096:
+            assert torch.equal(g1, g0)
+        else:
+            assert float((g1 - g0).double().norm() / g0.double().norm()) <= 1e-6
+        # (bf16 operands: a last-bit difference of a master weight can move its bf16 copy by 2^-9)
+        assert float((p1 - p0).double().norm() / p0.double().norm()) <= (1e-6 if dtype == "f32" else 5e-5)
+        np.testing.assert_allclose(l1, l0, rtol=2e-6 if dtype == "f32" else 1e-4)
