@@ -342,10 +342,14 @@ def main():
         coords, t, y = synth(n_obs, 2025 + rank, dev)       # each rank owns its shard of observations
     batches_per_epoch = max(n_obs // B, 1)
     shard = world > 1 and args.dp_mode == "shard"
-    eng = TrainStep(model, lr=2e-2, weight_decay=5e-4, grad_clip=10.0,
-                    ema_decay=1.0 - 1.0 / (10.0 * batches_per_epoch), max_batch=B,
-                    use_graph=args.graph and world == 1, force_dense=args.dense, dtype=args.dtype,
-                    shard_optimizer=shard)
+
+    def make_engine(shard_optimizer):
+        return TrainStep(model, lr=2e-2, weight_decay=5e-4, grad_clip=10.0,
+                         ema_decay=1.0 - 1.0 / (10.0 * batches_per_epoch), max_batch=B,
+                         use_graph=args.graph and world == 1, force_dense=args.dense, dtype=args.dtype,
+                         shard_optimizer=shard_optimizer)
+    eng = make_engine(shard)
+    dp_fallback = None
     perm = torch.randperm(n_obs, device=dev)
 
     def batch(i):
@@ -377,7 +381,20 @@ def main():
                             model.temporal_basis.centers, model.temporal_basis.bandwidths, cw_feats)
             torch.cuda.synchronize()
         del cw_feats
-    run(0, args.warmup)
+    try:
+        run(0, args.warmup)
+        torch.cuda.synchronize()
+    except Exception as e:                                   # noqa: BLE001
+        # N > 1 only: the sharded exchange (in-place reduce-scatter / all-gather) was refused by this build's
+        # collectives library -- a deterministic refusal is the same on every rank, so all of them fall back to the
+        # all-reduce exchange together; the line says so.  Anything else is re-raised.
+        if not shard:
+            raise
+        dp_fallback = f"{type(e).__name__}: {e}"[:300]
+        shard = False
+        args.dp_mode = "allreduce"
+        eng = make_engine(False)
+        run(0, args.warmup)
     # >= 1 timed windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and reduced
     # with MAX over ranks; `value` is the median window (a 20-step window is 2.4 ms: one window alone moves by a few
     # per cent from run to run with the chip's clock state), the fastest and slowest window are reported beside it
@@ -654,6 +671,8 @@ def main():
         if world > 1:
             # the one collective of the path, timed with events around it on the step's stream (rank 0's view;
             # it includes waiting for the slowest rank to arrive)
+            if dp_fallback:
+                out["dp_mode_fallback"] = {"requested": "shard", "used": "allreduce", "error": dp_fallback}
             out["collectives"] = {"dp_mode": args.dp_mode, "ms_per_step": allreduce_ms, "gradient_bytes": 4 * P_flat,
                                   "algorithm_bandwidth_GBs": 4 * P_flat / (allreduce_ms * 1e-3) / 1e9 if allreduce_ms else None,
                                   "note": "event brackets on the step's stream around every collective of a step (rank 0: "
