@@ -237,18 +237,23 @@ def dry_run():
     NOTHING -- the hook of the host-side sanitizer pass (tools/build_asan.sh, tests/test_host_sanitizer.py), which runs
     without a GPU.  Host tensors are then accepted as stand-ins for device buffers (the host never dereferences
     them); whatever comes out is meaningless.  Not a CPU path: without the variable host tensors raise."""
-    return os.environ.get("STDADK_DRY_RUN", "") == "1"
+    return _DRY_RUN
+
+
+# read once, as the library does (api.cpp reads it when it is loaded): a lookup in os.environ per tensor argument was
+# a fifth of the host time of a learnable-knot step (38 tensors per step)
+_DRY_RUN = os.environ.get("STDADK_DRY_RUN", "") == "1"
 
 
 def _on_device(tensor):
-    return tensor.is_cuda or dry_run()
+    return tensor.is_cuda or _DRY_RUN
 
 
 def _dev(tensor, name):
     """Validate a device tensor and return its address."""
     if tensor is None:
         return None
-    if dry_run() and not tensor.is_cuda:
+    if _DRY_RUN and not tensor.is_cuda:
         if not tensor.is_contiguous():
             raise RuntimeError(f"{name}: tensor must be contiguous")
         return tensor.data_ptr()
@@ -259,17 +264,26 @@ def _dev(tensor, name):
         raise RuntimeError(f"{name}: unsupported dtype {tensor.dtype}")
     if not tensor.is_contiguous():
         raise RuntimeError(f"{name}: tensor must be contiguous")
-    if tensor.device.index != torch.cuda.current_device():
+    if tensor.device.index != _current_device():
         # the launch stream is the CURRENT device's current stream (_stream below)
         raise RuntimeError(f"{name}: tensor lives on {tensor.device} but the current device is cuda:"
                            f"{torch.cuda.current_device()}; call under torch.cuda.device({tensor.device.index})")
     return tensor.data_ptr()
 
 
+# the raw accessors of torch (a tensor on a HIP device exists, so the runtime is initialised): current_device() and
+# current_stream() go through lazy initialisation checks and build a Stream object per call -- per tensor argument
+# and per native call that is tens of microseconds of a 0.11 ms step
+_current_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
     """The current HIP stream of the current device (every tensor of a call is checked to live there)."""
-    if dry_run() and not torch.cuda.is_available():
+    if _DRY_RUN and not torch.cuda.is_available():
         return None
+    if _raw_stream is not None:
+        return _raw_stream(_current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -200,6 +200,8 @@ class TrainStep:
         self.flat, self.offsets = flatten_parameters(model, transpose_first=True,
                                                      pad_multiple=32 * self.world if self.shard else 4)
         self.grad = torch.zeros_like(self.flat)
+        self._adam_groups = None        # cached descriptors of the two-group optimiser launch (_enqueue_optimizer)
+        self._knot_train = None         # ... and of the knot penalties
         self.chunk = self.flat.numel() // self.world if self.shard else self.flat.numel()
         self.lo = self.rank * self.chunk if self.shard else 0
         self.hi = self.lo + self.chunk
@@ -538,9 +540,14 @@ class TrainStep:
                                   self.loss_sum if self.nc_lambda != 0.0 else None)
         if self.learnable:
             sb = self.model.spatial_basis
-            kt = N.make_knot_train(sb.centers_init, sb.gradient_damping, sb.damping_threshold,
-                                   sb.damping_strength, self.domain_w, self.movement_w,
-                                   penalty_grad_scale=1.0 / self.world, penalty_loss_scale=float(B * Q))
+            kkey = (sb.centers_init.data_ptr(), sb.gradient_damping, sb.damping_threshold, sb.damping_strength,
+                    self.domain_w, self.movement_w, self.world, B * Q)
+            if self._knot_train is None or self._knot_train[0] != kkey:
+                self._knot_train = (kkey, N.make_knot_train(sb.centers_init, sb.gradient_damping, sb.damping_threshold,
+                                                            sb.damping_strength, self.domain_w, self.movement_w,
+                                                            penalty_grad_scale=1.0 / self.world,
+                                                            penalty_loss_scale=float(B * Q)))
+            kt = self._knot_train[1]
             N.knot_backward(st.basis, st.desc, st.params, coords, B, ws, st.flags, kt,
                             self.g_centers, self.g_log_bw, self.loss_sum)
         if self._sparsity is not None:
@@ -554,15 +561,23 @@ class TrainStep:
         ke = self.knot_end
         watch = self.loss_sum if self.nonfinite is not None else None
         if ke and self.grad_clip > 0:
-            # learnable knots: both groups' clip norms in one launch, both AdamW/EMA updates in one launch
-            N.sumsq2(self.grad[ke:], self.sumsq, self.grad[:ke], self.sumsq_basis, step_inc=self.step_dev)
+            # learnable knots: both groups' clip norms in one launch, both AdamW/EMA updates in one launch.
+            # The two group descriptors (14 buffer addresses, 10 slices) only change when a buffer or a rate does:
+            # rebuilt per step they were a quarter of this path's host time, and this path is host-bound.
             ema = self.ema
-            g_mlp = N.make_adam_group(self.flat[ke:], self.grad[ke:], self.m[ke:], self.v[ke:],
-                                      ema[ke:] if ema is not None else None, self.lr, self.lr_dev, self.grad_clip,
-                                      self.sumsq, shadow=self._shadow(ke))
-            g_knot = N.make_adam_group(self.flat[:ke], self.grad[:ke], self.m[:ke], self.v[:ke],
-                                       ema[:ke] if ema is not None else None, self.basis_lr, self.basis_lr_dev,
-                                       self.basis_clip, self.sumsq_basis)
+            key = (self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                   ema.data_ptr() if ema is not None else 0, self.lr, self.basis_lr, self.grad_clip, self.basis_clip,
+                   ke, id(self.lr_dev), id(self.basis_lr_dev), len(self._shadow_regions))
+            if self._adam_groups is None or self._adam_groups[0] != key:
+                g_mlp = N.make_adam_group(self.flat[ke:], self.grad[ke:], self.m[ke:], self.v[ke:],
+                                          ema[ke:] if ema is not None else None, self.lr, self.lr_dev, self.grad_clip,
+                                          self.sumsq, shadow=self._shadow(ke))
+                g_knot = N.make_adam_group(self.flat[:ke], self.grad[:ke], self.m[:ke], self.v[:ke],
+                                           ema[:ke] if ema is not None else None, self.basis_lr, self.basis_lr_dev,
+                                           self.basis_clip, self.sumsq_basis)
+                self._adam_groups = (key, g_mlp, g_knot, self.grad[ke:], self.grad[:ke])
+            _, g_mlp, g_knot, gv_mlp, gv_knot = self._adam_groups
+            N.sumsq2(gv_mlp, self.sumsq, gv_knot, self.sumsq_basis, step_inc=self.step_dev)
             N.adamw_ema2(g_mlp, g_knot, self.betas, self.eps, self.wd, self.step_count + 1,
                          ema_decay=self.ema_decay, step_dev=self.step_dev, loss_watch=watch,
                          nonfinite_step=self.nonfinite)
