@@ -200,6 +200,7 @@ class TrainStep:
         self.flat, self.offsets = flatten_parameters(model, transpose_first=True,
                                                      pad_multiple=32 * self.world if self.shard else 4)
         self.grad = torch.zeros_like(self.flat)
+        self._shard_cache = None        # cached slices / descriptors of the sharded optimiser (_shard_views)
         self._adam_groups = None        # cached descriptors of the two-group optimiser launch (_enqueue_optimizer)
         self._knot_train = None         # ... and of the knot penalties
         self.chunk = self.flat.numel() // self.world if self.shard else self.flat.numel()
@@ -441,53 +442,68 @@ class TrainStep:
         """This rank's part of the flat range [a, b): (start, stop) in flat coordinates, stop <= start if empty."""
         return max(a, self.lo), min(b, self.hi)
 
+    def _shard_views(self):
+        """Slices and optimiser descriptors of this rank's part of the flat buffers -- rebuilt only when a buffer, a
+        boundary or a rate changes (a dozen slices and up to 14 address checks per step otherwise, on a path whose
+        host side also has three collectives to enqueue per step)."""
+        ke, lo = self.knot_end, self.lo
+        ema = self.ema
+        key = (self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+               ema.data_ptr() if ema is not None else 0, lo, self.hi, ke, self.lr, self.grad_clip, id(self.lr_dev)) + \
+              ((self.basis_lr, self.basis_clip, id(self.basis_lr_dev)) if ke else ())
+        c = self._shard_cache
+        if c is not None and c["key"] == key:
+            return c
+        clip = self.grad_clip > 0
+        a0, b0 = self._local(ke, self.flat.numel())
+        a1, b1 = self._local(0, ke) if ke else (0, 0)
+
+        def bufs(a, b):
+            return (self.flat[a:b], self.grad[a:b], self.m[a - lo:b - lo], self.v[a - lo:b - lo],
+                    ema[a - lo:b - lo] if ema is not None else None)
+        c = {"key": key, "g_mlp": self.grad[a0:max(b0, a0)], "g_knot": self.grad[a1:max(b1, a1)] if ke else None,
+             "groups": [], "single": None}
+        if b0 > a0:
+            c["groups"].append(N.make_adam_group(*bufs(a0, b0), self.lr, self.lr_dev, self.grad_clip if clip else 0.0,
+                                                 self.sumsq if clip else None))
+        if ke and b1 > a1:
+            c["groups"].append(N.make_adam_group(*bufs(a1, b1), self.basis_lr, self.basis_lr_dev,
+                                                 self.basis_clip if clip else 0.0, self.sumsq_basis if clip else None))
+        if len(c["groups"]) == 1:
+            mlp = b0 > a0
+            c["single"] = (bufs(a0, b0) if mlp else bufs(a1, b1), c["groups"][0].lr, c["groups"][0].max_norm,
+                           self.sumsq if mlp else self.sumsq_basis, self.lr_dev if mlp else self.basis_lr_dev)
+        self._shard_cache = c
+        return c
+
     def _shard_sumsq(self):
         """Sum of squares of the REDUCED gradient on this rank's slice, per parameter group, into the 2 x 256
         partials of `_sumsq_all` (a group this rank holds nothing of contributes zeros); advances the device step
         counter once.  The SUM of the ranks' partial vectors gives the global clip norms."""
-        ke = self.knot_end
-        a0, b0 = self._local(ke, self.flat.numel())
-        g_mlp = self.grad[a0:max(b0, a0)]
         if self.grad_clip <= 0:
             N.step_advance(self.step_dev)
             return
-        if ke:
-            a1, b1 = self._local(0, ke)
-            N.sumsq2(g_mlp, self.sumsq, self.grad[a1:max(b1, a1)], self.sumsq_basis, step_inc=self.step_dev)
+        c = self._shard_views()
+        if self.knot_end:
+            N.sumsq2(c["g_mlp"], self.sumsq, c["g_knot"], self.sumsq_basis, step_inc=self.step_dev)
         else:
-            N.sumsq(g_mlp, self.sumsq, step_inc=self.step_dev)
+            N.sumsq(c["g_mlp"], self.sumsq, step_inc=self.step_dev)
 
     def _shard_adamw(self):
         """AdamW + EMA on this rank's slice (moments / EMA shadow indexed from `lo`), each group with its own learning
         rate and its GLOBAL clip norm (the summed partials in `_sumsq_all`)."""
-        ke, lo = self.knot_end, self.lo
-        clip = self.grad_clip > 0
-        ema = self.ema
-
-        def group(a, b, lr, lr_dev, max_norm, parts):
-            return N.make_adam_group(self.flat[a:b], self.grad[a:b], self.m[a - lo:b - lo], self.v[a - lo:b - lo],
-                                     ema[a - lo:b - lo] if ema is not None else None, lr, lr_dev,
-                                     max_norm if clip else 0.0, parts if clip else None)
-        a0, b0 = self._local(ke, self.flat.numel())
-        a1, b1 = self._local(0, ke)
-        groups = []
-        if b0 > a0:
-            groups.append(group(a0, b0, self.lr, self.lr_dev, self.grad_clip, self.sumsq))
-        if ke and b1 > a1:
-            groups.append(group(a1, b1, self.basis_lr, self.basis_lr_dev, self.basis_clip, self.sumsq_basis))
+        c = self._shard_views()
         watch = self.loss_sum if self.nonfinite is not None else None
+        groups = c["groups"]
         if len(groups) == 2:
             N.adamw_ema2(groups[0], groups[1], self.betas, self.eps, self.wd, self.step_count + 1,
                          ema_decay=self.ema_decay, step_dev=self.step_dev, loss_watch=watch,
                          nonfinite_step=self.nonfinite)
         elif groups:
-            g = groups[0]
-            a, b = (a0, b0) if b0 > a0 else (a1, b1)
-            N.adamw_ema(self.flat[a:b], self.grad[a:b], self.m[a - lo:b - lo], self.v[a - lo:b - lo],
-                        ema[a - lo:b - lo] if ema is not None else None, g.lr, self.betas, self.eps, self.wd,
-                        self.step_count + 1, max_norm=g.max_norm, sumsq_parts=self.sumsq if b0 > a0 else self.sumsq_basis,
-                        ema_decay=self.ema_decay, lr_dev=self.lr_dev if b0 > a0 else self.basis_lr_dev,
-                        step_dev=self.step_dev, loss_watch=watch, nonfinite_step=self.nonfinite)
+            (p_, g_, m_, v_, e_), lr, max_norm, parts, lr_dev = c["single"]
+            N.adamw_ema(p_, g_, m_, v_, e_, lr, self.betas, self.eps, self.wd, self.step_count + 1, max_norm=max_norm,
+                        sumsq_parts=parts, ema_decay=self.ema_decay, lr_dev=lr_dev, step_dev=self.step_dev,
+                        loss_watch=watch, nonfinite_step=self.nonfinite)
 
     def _enqueue_sharded_optimizer(self):
         """reduce-scatter(gradient) -> local sum of squares -> all-reduce(2 x 256 partials) -> AdamW/EMA on the slice
