@@ -9,7 +9,8 @@ in HBM: feature build (multi-resolution Wendland + Gaussian bases) -> MLP forwar
 scaling: per-GPU batch fixed), launched by torch.distributed.run -- or by this script itself: `python bench.py
 --gpus N` with WORLD_SIZE unset starts the N ranks as child processes BEFORE anything touches a GPU and relays
 rank 0's line.  Gradient exchange per step (--dp-mode): `shard` = reduce-scatter + sharded AdamW/EMA + all-gather,
-`allreduce` = one all-reduce + replicated optimiser; the other mode is reported beside the headline.
+`allreduce` = one all-reduce + replicated optimiser (`auto` = whichever is faster in a 100-step calibration, both times
+in `dp_mode_calibration`); default `shard`, the other mode is reported beside the headline.
 Rank 0 prints ONE JSON line:
   value      whole-job observations/s: the MEDIAN of >= 10 timed windows of K steps each (every window bracketed by
              barrier + synchronize, max over ranks); min / max of the windows beside it
@@ -300,8 +301,11 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the extra per-GPU batch sizes (N = 1 only)")
     ap.add_argument("--windows", type=int, default=10,
                     help="timed windows of --steps steps each; `value` is the median window (>= 1)")
-    ap.add_argument("--dp-mode", default="shard", choices=["shard", "allreduce"],
-                    help="N > 1: gradient exchange of the headline line (the other mode is reported beside it)")
+    ap.add_argument("--dp-mode", default="shard", choices=["shard", "allreduce", "auto"],
+                    help="N > 1: gradient exchange of the headline line (the other mode is reported beside it); auto = "
+                         "whichever of the two is faster in a short calibration on this machine (both times reported; "
+                         "not the default: in the two-rank gloo rehearsal the second engine of the calibration left "
+                         "the first one slower)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -341,10 +345,13 @@ def main():
     else:
         coords, t, y = synth(n_obs, 2025 + rank, dev)       # each rank owns its shard of observations
     batches_per_epoch = max(n_obs // B, 1)
+    dp_auto = world > 1 and args.dp_mode == "auto"
+    if args.dp_mode == "auto":
+        args.dp_mode = "shard"                 # calibrated against all-reduce below (N > 1)
     shard = world > 1 and args.dp_mode == "shard"
 
-    def make_engine(shard_optimizer):
-        return TrainStep(model, lr=2e-2, weight_decay=5e-4, grad_clip=10.0,
+    def make_engine(shard_optimizer, mdl=None):
+        return TrainStep(model if mdl is None else mdl, lr=2e-2, weight_decay=5e-4, grad_clip=10.0,
                          ema_decay=1.0 - 1.0 / (10.0 * batches_per_epoch), max_batch=B,
                          use_graph=args.graph and world == 1, force_dense=args.dense, dtype=args.dtype,
                          shard_optimizer=shard_optimizer)
@@ -356,14 +363,15 @@ def main():
         idx = perm[(i % batches_per_epoch) * B:(i % batches_per_epoch) * B + B]
         return coords[idx], t[idx], y[idx]
 
-    def run(k0, k):
+    def run(k0, k, e=None):
         # the observation shard stays resident in HBM; a step takes the index slice of its batch
+        e = eng if e is None else e
         for i in range(k0, k0 + k):
             j, jn = i % batches_per_epoch, (i + 1) % batches_per_epoch
             # the next batch's rows are announced so that its gather + binning run on a side stream
             # while this step computes (software pipelining of the batch preparation)
-            eng.step_indexed(coords, t, y, perm[j * B:j * B + B], global_rows=B * world,
-                             next_idx=None if args.no_pipeline else perm[jn * B:jn * B + B])
+            e.step_indexed(coords, t, y, perm[j * B:j * B + B], global_rows=B * world,
+                           next_idx=None if args.no_pipeline else perm[jn * B:jn * B + B])
 
     # device warm-up BEFORE the W warm-up steps: the chip's power state takes ~15 ms of load to settle and falls back
     # within 20 ms of idling (tools/startup_latency.py: a step's kernels all run ~6 % slower during the first ~100
@@ -395,6 +403,40 @@ def main():
         args.dp_mode = "allreduce"
         eng = make_engine(False)
         run(0, args.warmup)
+    # --dp-mode auto (N > 1): the sharded exchange is three collectives per step, the all-reduce one; which of them is
+    # faster for an 11 MB gradient depends on the machine's collectives (latency against the optimiser traffic saved).
+    # Both are timed on 100 steps (barrier + synchronize brackets, MAX over ranks -- so every rank decides alike), the
+    # all-reduce engine on a second model of the same shape so that the headline model stays bound to ITS engine.
+    dp_calibration = None
+    if dp_auto and dp_fallback is None:
+        def quick(e, k=100):
+            run(0, 5, e)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(5, k, e)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            tm = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            return tm.item() / k * 1e3
+        t_shard = quick(eng)
+        torch.manual_seed(0)
+        model_b = STInterpMLP(p=0, k_spatial_centers=wl["k_spatial_centers"],
+                              k_temporal_centers=wl["k_temporal_centers"], hidden_dims=wl["hidden_dims"],
+                              dropout=args.dropout, layernorm=True).to(dev)
+        model_b.train()
+        eng_b = make_engine(False, model_b)
+        t_ar = quick(eng_b)
+        del eng_b, model_b
+        gc.collect()
+        torch.cuda.synchronize()
+        dp_calibration = {"steps": 100, "shard_ms_per_step": t_shard, "allreduce_ms_per_step": t_ar}
+        if t_ar < t_shard:
+            shard = False
+            args.dp_mode = "allreduce"
+            eng = make_engine(False)
+            run(0, args.warmup)
+            torch.cuda.synchronize()
+        dp_calibration["chosen"] = args.dp_mode
     # >= 1 timed windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and reduced
     # with MAX over ranks; `value` is the median window (a 20-step window is 2.4 ms: one window alone moves by a few
     # per cent from run to run with the chip's clock state), the fastest and slowest window are reported beside it
@@ -671,6 +713,8 @@ def main():
         if world > 1:
             # the one collective of the path, timed with events around it on the step's stream (rank 0's view;
             # it includes waiting for the slowest rank to arrive)
+            if dp_calibration:
+                out["dp_mode_calibration"] = dp_calibration
             if dp_fallback:
                 out["dp_mode_fallback"] = {"requested": "shard", "used": "allreduce", "error": dp_fallback}
             out["collectives"] = {"dp_mode": args.dp_mode, "ms_per_step": allreduce_ms, "gradient_bytes": 4 * P_flat,
