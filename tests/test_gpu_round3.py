@@ -451,3 +451,28 @@ def test_reductions_inside_the_weight_gradient_launch(name, B, dtype, monkeypatc
         # (bf16 operands: a last-bit difference of a master weight can move its bf16 copy by 2^-9)
         assert float((p1 - p0).double().norm() / p0.double().norm()) <= (1e-6 if dtype == "f32" else 5e-5)
         np.testing.assert_allclose(l1, l0, rtol=2e-6 if dtype == "f32" else 1e-4)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_large_batch_steps_are_reproducible_run_to_run(dropout):
+    """65 536 rows take the weight-gradient launch with the reductions inside (arrival counters, last K slice sums):
+    which workgroup arrives last differs from run to run, the sums may not -- two runs of three whole steps from the
+    same state end in bit-identical parameters (the loss sum is accumulated with float atomics: compared to rounding)."""
+    from stnf.engine import TrainStep
+    if any(os.environ.get(k) for k in ("STDADK_NO_DW_ALL", "STDADK_NO_FUSED_TAIL")):
+        pytest.skip("the merged weight-gradient launch is switched off")
+    cfg = dict(cases.MODEL_CASES["c2_b257"], B=65536, seed=3)
+    d = dev()
+    X, coords, t, y = (torch.from_numpy(a).to(d) if a is not None else None for a in cases.make_inputs(cfg))
+    res = []
+    for _ in range(2):
+        m = T.build_model(cfg, dropout=dropout).train()
+        eng = TrainStep(m, lr=1e-3, grad_clip=0.5, max_batch=cfg["B"], seed=7)
+        for _ in range(3):
+            eng.step(None, coords, t.view(-1), y)
+        torch.cuda.synchronize()
+        res.append((eng.flat.clone(), eng.mean_loss()))
+        del eng, m
+    assert torch.isfinite(res[0][0]).all()
+    assert torch.equal(res[0][0], res[1][0])
+    assert abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[0][1])
