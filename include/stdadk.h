@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STDADK_ABI_VERSION 7
+#define STDADK_ABI_VERSION 8
 #define STDADK_MAX_HIDDEN 8
 #define STDADK_MAX_LEVELS 8
 #define STDADK_SUMSQ_PARTS 256 /* partial sums written by stdadk_sumsq_f32 */
@@ -459,6 +459,22 @@ int stdadk_train_step_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc 
                           const stdadk_sparsity_desc *sparsity, float *loss_sum, void *workspace,
                           size_t workspace_bytes, uint64_t drop_seed, int32_t flags,
                           const stdadk_optim_desc *opt, stdadk_stream_t stream);
+
+/* stdadk_train_step_f32 on rows `idx` of the RESIDENT arrays, which also prepares the NEXT batch (ABI 8): when the
+ * next batch takes the one-launch binning of small batches (window path, next_B <= 8192), rows next_idx of the
+ * same arrays are binned into `next_workspace` by extra workgroups of this step's optimiser launch -- no launch of
+ * its own, no second stream -- and *next_binned is set to 1: the caller then steps on next_workspace with
+ * STDADK_FLAG_PREBINNED (as after stdadk_bin_batch_f32).  Otherwise *next_binned = 0 and nothing was prepared.
+ * The resident arrays are always given (also when THIS step runs with STDADK_FLAG_PREBINNED: it reads its rows from
+ * `workspace` then); next_y_cols as y_cols of stdadk_bin_batch_f32.  next_workspace must not be `workspace`. */
+int stdadk_train_step_next_f32(const stdadk_basis_desc *basis, const stdadk_mlp_desc *mlp,
+                               const stdadk_mlp_tensors *params, const stdadk_mlp_tensors *grads,
+                               const float *coords_all, const float *t_all, const float *X_all, const float *y_all,
+                               const int64_t *idx, int64_t B, float grad_scale, const stdadk_loss_desc *loss,
+                               const stdadk_sparsity_desc *sparsity, float *loss_sum, void *workspace,
+                               size_t workspace_bytes, uint64_t drop_seed, int32_t flags, const stdadk_optim_desc *opt,
+                               const int64_t *next_idx, int64_t next_B, int32_t next_y_cols, void *next_workspace,
+                               size_t next_workspace_bytes, int32_t *next_binned, stdadk_stream_t stream);
 
 /* A10 on a site x time prediction grid (the dense inference callers loop over time slices with the SAME S
  * sites in each, scripts/train_st_interp.py:1091-1107,1232-1248,1378-1409).  Layer 0's pre-activation of row

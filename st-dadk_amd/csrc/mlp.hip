@@ -12,6 +12,8 @@
 #include "gemm_f32.h"
 #include "window.h"
 #include "tail.h"
+#include "optim.h"
+#include "bin_body.h"
 #include "knots.h"
 #include "basis.h"
 
@@ -1646,14 +1648,16 @@ static int train_fwd_bwd_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc 
   return rc;
 }
 
-extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
-                                     const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
-                                     const float *coords, const float *t, const float *X, const float *y,
-                                     const int64_t *idx, int64_t B, float grad_scale,
-                                     const stdadk_loss_desc *loss, const stdadk_sparsity_desc *sparsity,
-                                     float *loss_sum, void *workspace, size_t workspace_bytes,
-                                     uint64_t drop_seed, int32_t flags, const stdadk_optim_desc *o,
-                                     stdadk_stream_t stream) {
+static int train_step_impl(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                           const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
+                           const float *coords, const float *t, const float *X, const float *y,
+                           const int64_t *idx, int64_t B, float grad_scale,
+                           const stdadk_loss_desc *loss, const stdadk_sparsity_desc *sparsity,
+                           float *loss_sum, void *workspace, size_t workspace_bytes,
+                           uint64_t drop_seed, int32_t flags, const stdadk_optim_desc *o,
+                           stdadk_stream_t stream, const int64_t *next_idx, int64_t next_B, int32_t next_y_cols,
+                           void *next_workspace, size_t next_workspace_bytes, int32_t *next_binned) {
+  if (next_binned) *next_binned = 0;
   STDADK_REQUIRE(o && o->p && o->g && o->m && o->v && o->n > 0 && o->step_dev, STDADK_E_ARG,
                  "train_step: optimiser descriptor incomplete");
   STDADK_REQUIRE(o->max_norm <= 0.f || o->sumsq_parts, STDADK_E_ARG, "train_step: max_norm > 0 needs sumsq_parts");
@@ -1687,10 +1691,59 @@ extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_ml
     rc = stdadk_step_advance(o->step_dev, stream);
     if (rc) return rc;
   }
+  if (next_idx && next_B > 0 && next_workspace && next_binned) {
+    // the NEXT batch's binning inside this step's optimiser launch (optim.hip: adamw_bin_kernel), when it is the
+    // one-launch binning of small batches; the caller then steps on `next_workspace` with STDADK_FLAG_PREBINNED
+    Ctx cn;
+    bool window_n = false;
+    rc = step_common(cn, b, d, next_B, next_workspace, next_workspace_bytes, flags & ~STDADK_FLAG_PREBINNED, &window_n);
+    if (rc) return rc;
+    if (window_n && bin_small_eligible((int)next_B, cn.pl.G) && coords && t && (b->p == 0 || X)) {
+      STDADK_REQUIRE(next_y_cols >= 0 && next_y_cols <= d->out_dim && (next_y_cols == 0 || y), STDADK_E_ARG,
+                     "train_step: next_y_cols=%d must be in 0..Q with y given", next_y_cols);
+      const BinBuffers bb = plan_bins(cn.ws, cn.pl);
+      const BinSmallArgs ba = bin_small_args(coords, t, next_y_cols > 0 ? y : nullptr, next_y_cols, X, b->p, (int)next_B,
+                                             cn.pl.G, bb, next_idx);
+      rc = adamw_ema_with_binning(o->p, o->g, o->m, o->v, o->ema, o->n, o->lr, o->lr_dev, o->beta1, o->beta2, o->eps,
+                                  o->weight_decay, o->step_dev, o->max_norm, clip ? parts : nullptr, n_parts,
+                                  o->ema_decay, o->shadow, o->nonfinite_step ? loss_sum : nullptr, o->nonfinite_step,
+                                  stream, ba);
+      if (rc == 0) *next_binned = 1;
+      return rc;
+    }
+  }
   return stdadk_adamw_ema_f32(o->p, o->g, o->m, o->v, o->ema, o->n, o->lr, o->lr_dev, o->beta1, o->beta2, o->eps,
                               o->weight_decay, 1, o->step_dev, o->max_norm, clip ? parts : nullptr, n_parts,
                               1.0f, o->ema_decay, o->shadow, o->nonfinite_step ? loss_sum : nullptr, o->nonfinite_step,
                               stream);
+}
+
+extern "C" int stdadk_train_step_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                     const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
+                                     const float *coords, const float *t, const float *X, const float *y,
+                                     const int64_t *idx, int64_t B, float grad_scale,
+                                     const stdadk_loss_desc *loss, const stdadk_sparsity_desc *sparsity,
+                                     float *loss_sum, void *workspace, size_t workspace_bytes,
+                                     uint64_t drop_seed, int32_t flags, const stdadk_optim_desc *o,
+                                     stdadk_stream_t stream) {
+  return train_step_impl(b, d, P, G, coords, t, X, y, idx, B, grad_scale, loss, sparsity, loss_sum, workspace,
+                         workspace_bytes, drop_seed, flags, o, stream, nullptr, 0, 0, nullptr, 0, nullptr);
+}
+
+extern "C" int stdadk_train_step_next_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,
+                                          const stdadk_mlp_tensors *P, const stdadk_mlp_tensors *G,
+                                          const float *coords_all, const float *t_all, const float *X_all,
+                                          const float *y_all, const int64_t *idx, int64_t B, float grad_scale,
+                                          const stdadk_loss_desc *loss, const stdadk_sparsity_desc *sparsity,
+                                          float *loss_sum, void *workspace, size_t workspace_bytes,
+                                          uint64_t drop_seed, int32_t flags, const stdadk_optim_desc *o,
+                                          const int64_t *next_idx, int64_t next_B, int32_t next_y_cols,
+                                          void *next_workspace, size_t next_workspace_bytes, int32_t *next_binned,
+                                          stdadk_stream_t stream) {
+  STDADK_REQUIRE(next_binned, STDADK_E_ARG, "train_step_next: next_binned is NULL");
+  return train_step_impl(b, d, P, G, coords_all, t_all, X_all, y_all, idx, B, grad_scale, loss, sparsity, loss_sum,
+                         workspace, workspace_bytes, drop_seed, flags, o, stream, next_idx, next_B, next_y_cols,
+                         next_workspace, next_workspace_bytes, next_binned);
 }
 
 extern "C" int stdadk_bin_batch_f32(const stdadk_basis_desc *b, const stdadk_mlp_desc *d,

@@ -2,6 +2,8 @@
 // per parameter).  Replaces scripts/train_st_interp.py:696-712 (clip_grad_norm_, optimizer.step,
 // ema.update), torch.optim.AdamW's update rule and stnf/utils/ema.py:52-66.
 #include "common.h"
+#include "bin_body.h"
+#include "optim.h"
 
 #include <stdlib.h>
 
@@ -168,12 +170,15 @@ __device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int blo
   }
   float coef = 1.f;
   if (a.max_norm > 0.f && a.sumsq) {
-    // block-wide sum of the partials, same order in every block (L2-resident, a few hundred floats)
+    // block-wide sum of the partials, same order in every block (L2-resident, a few hundred floats): by the first
+    // 256 threads whatever the block size, so that the value does not depend on the launch shape
     __shared__ float red[4];
     float ss = 0.f;
-    for (int i = threadIdx.x; i < a.n_parts; i += 256) ss += a.sumsq[i];
-    ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    if (threadIdx.x < 256) {
+      for (int i = threadIdx.x; i < a.n_parts; i += 256) ss += a.sumsq[i];
+      ss = wave_sum(ss);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    }
     __syncthreads();
     ss = (red[0] + red[1]) + (red[2] + red[3]);
     coef = fminf(1.f, a.max_norm / (sqrtf(ss) + 1e-6f));
@@ -241,6 +246,18 @@ __global__ __launch_bounds__(256) void adamw_ema2_kernel(AdamArgs a0, AdamArgs a
   else adamw_ema_block(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
 }
 
+// The optimiser launch of a step that also bins the NEXT batch (bin_body.h): workgroups [0, n_bin) are the
+// independent binning workgroups (1024 threads, 68-100 KiB of dynamic LDS -- which every workgroup of the launch then
+// reserves: two workgroups per CU up to 4 096 rows, one beyond, so the optimiser part runs as 1024-thread workgroups
+// too, with five float4 loads in flight per thread), the rest update the parameters.  The binning's latency chain (~10 us on eight
+// workgroups) hides under the optimiser's HBM stream; the batch preparation needs no launch on the step's critical
+// path, no side stream and none of its cross-stream packets (profiles/r03_step_timeline.txt: 6-7 us per step).
+__global__ __launch_bounds__(1024) void adamw_bin_kernel(AdamArgs a, BinSmallArgs b, int n_bin) {
+  extern __shared__ __attribute__((aligned(16))) int bin_smem[];
+  if ((int)blockIdx.x < n_bin) { bin_small_body(b, (int)blockIdx.x, n_bin, bin_smem); return; }
+  adamw_ema_block(a, (int)blockIdx.x - n_bin, (int)gridDim.x - n_bin);
+}
+
 __global__ void step_advance_kernel(int *s) { s[0] += 1; }
 
 }  // namespace stdadk
@@ -273,12 +290,13 @@ extern "C" int stdadk_sumsq_f32(const float *g, int64_t n, float *parts, int32_t
   return 0;
 }
 
-extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
-                                    float lr, const float *lr_dev, float beta1, float beta2, float eps,
-                                    float weight_decay, int32_t step, const int32_t *step_dev, float max_norm,
-                                    const float *sumsq_parts, int32_t n_parts, float grad_mul,
-                                    float ema_decay, const stdadk_bf16_shadow *shadow,
-                                    const float *loss_watch, int32_t *nonfinite_step, stdadk_stream_t stream) {
+static int adamw_impl(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
+                      float lr, const float *lr_dev, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t step, const int32_t *step_dev, float max_norm,
+                      const float *sumsq_parts, int32_t n_parts, float grad_mul,
+                      float ema_decay, const stdadk_bf16_shadow *shadow,
+                      const float *loss_watch, int32_t *nonfinite_step, stdadk_stream_t stream,
+                      const stdadk::BinSmallArgs *bin) {
   STDADK_REQUIRE(n >= 0, STDADK_E_ARG, "adamw: negative n");
   STDADK_REQUIRE((loss_watch != nullptr) == (nonfinite_step != nullptr), STDADK_E_ARG,
                  "adamw: loss_watch and nonfinite_step go together (both or neither)");
@@ -301,10 +319,50 @@ extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v
   int64_t blocks = ceil_div(n, 256 * 4);
   if (blocks > 1536) blocks = 1536;
   { const char *e = getenv("STDADK_ADAMW_BLOCKS"); if (e && atoi(e) > 0) blocks = atoi(e); }   // measurement aid
+  if (bin) {
+    // one resident round of 1024-thread workgroups (the dynamic LDS of the binning allows one per CU): the binning
+    // workgroups first, the optimiser on the other CUs
+    const int n_bin = bin->B >= 1024 ? SMALL_WG : 1;
+    const size_t lds = (size_t)bin_small_lds_ints(bin->B) * sizeof(int);
+    const int per_cu = lds <= 78 * 1024 ? 2 : 1;               // workgroups of this launch a CU holds (160 KiB of LDS)
+    int64_t ab = ceil_div(n, 1024 * 4);
+    if (ab > 256 * per_cu - n_bin) ab = 256 * per_cu - n_bin;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void *>(adamw_bin_kernel), BIN_SMALL_LDS_INTS * (int)sizeof(int));
+      if (e != hipSuccess) { set_error("adamw_bin: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+      attr = true;
+    }
+    STDADK_LAUNCH_NAMED("adamw_bin_kernel", adamw_bin_kernel, dim3((unsigned)(ab + n_bin)), dim3(1024), lds,
+                        (hipStream_t)stream, a, *bin, n_bin);
+    STDADK_CHECK_LAUNCH("adamw_bin");
+    return 0;
+  }
   STDADK_LAUNCH(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   STDADK_CHECK_LAUNCH("adamw_ema");
   return 0;
 }
+
+extern "C" int stdadk_adamw_ema_f32(float *p, const float *g, float *m, float *v, float *ema, int64_t n,
+                                    float lr, const float *lr_dev, float beta1, float beta2, float eps,
+                                    float weight_decay, int32_t step, const int32_t *step_dev, float max_norm,
+                                    const float *sumsq_parts, int32_t n_parts, float grad_mul,
+                                    float ema_decay, const stdadk_bf16_shadow *shadow,
+                                    const float *loss_watch, int32_t *nonfinite_step, stdadk_stream_t stream) {
+  return adamw_impl(p, g, m, v, ema, n, lr, lr_dev, beta1, beta2, eps, weight_decay, step, step_dev, max_norm,
+                    sumsq_parts, n_parts, grad_mul, ema_decay, shadow, loss_watch, nonfinite_step, stream, nullptr);
+}
+
+namespace stdadk {
+int adamw_ema_with_binning(float *p, const float *g, float *m, float *v, float *ema, int64_t n, float lr,
+                           const float *lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                           const int32_t *step_dev, float max_norm, const float *sumsq_parts, int32_t n_parts,
+                           float ema_decay, const stdadk_bf16_shadow *shadow, const float *loss_watch,
+                           int32_t *nonfinite_step, stdadk_stream_t stream, const BinSmallArgs &bin) {
+  return adamw_impl(p, g, m, v, ema, n, lr, lr_dev, beta1, beta2, eps, weight_decay, 1, step_dev, max_norm, sumsq_parts,
+                    n_parts, 1.0f, ema_decay, shadow, loss_watch, nonfinite_step, stream, &bin);
+}
+}  // namespace stdadk
 
 static int fill_group(AdamArgs &a, const stdadk_adam_group *gr, float beta1, float beta2, float eps, float wd,
                       int32_t step, const int32_t *step_dev, float grad_mul, float ema_decay) {

@@ -39,6 +39,11 @@ struct BinBuffers {
 };
 
 int pick_cell_grid(int64_t B);   // G: cells per axis, power of two in [8, 256]
+struct BinSmallArgs;
+// the one-launch binning of small batches (bin_body.h) as arguments another launch can carry
+BinSmallArgs bin_small_args(const float *coords, const float *t, const float *y, int Q, const float *X, int p, int B,
+                            int G, const BinBuffers &bb, const int64_t *idx);
+bool bin_small_eligible(int B, int G);
 
 // idx (optional): the batch is rows idx[b] of resident arrays coords/t/y/X; perm holds batch positions
 int bin_obs(const float *coords, const float *t, const float *y, int Q, const float *X, int p,

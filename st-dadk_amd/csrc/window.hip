@@ -12,6 +12,7 @@
 // Integer bookkeeping (cell keys, sorted permutation, window origins) follows the bit-exact contract
 // written in include/stdadk.h (pinned by tests); phi uses the same arithmetic as rbf_build.hip.
 #include "window.h"
+#include "bin_body.h"
 
 #include "basis.h"
 #include "l1_body.h"
@@ -159,131 +160,36 @@ __global__ void zero_ints_kernel(int *__restrict__ p, int n) {
 // in-cell order is by original index, so the workgroups' different atomic arrival orders do not show).  What is
 // split -- the ordering loops and the dependent row gathers of the emission -- is the longer half of the
 // single-workgroup kernel's latency chain (MI355X, B = 4096: 21 us with one workgroup).
-constexpr int SMALL_B = 8192, SMALL_G = 64, SMALL_WG = 8;
-__global__ __launch_bounds__(1024) void bin_small_kernel(const int64_t *__restrict__ idx,
-                                                         const float *__restrict__ coords,
-                                                         const float *__restrict__ t,
-                                                         const float *__restrict__ y, int Q,
-                                                         const float *__restrict__ X, int p, int B, int G,
-                                                         int *__restrict__ keys, int *__restrict__ cell_start,
-                                                         int *__restrict__ perm, float *__restrict__ xs,
-                                                         float *__restrict__ ys, float *__restrict__ ts,
-                                                         float *__restrict__ y_s, float *__restrict__ X_s) {
-  __shared__ int hist[SMALL_G * SMALL_G];      // counts, then running cursors
-  __shared__ int start[SMALL_G * SMALL_G + 1];
-  __shared__ int ptmp[SMALL_B];                // unordered permutation
-  __shared__ int pfin[SMALL_B];                // ordered permutation
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  const int ncell = G * G;
-  constexpr int PER_T = SMALL_B / 1024;        // observations per thread
-  // this workgroup's slice [lo, hi) of the batch positions (keys) and of the sorted positions (everything else)
-  const int per_wg = ((B + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63;
-  const int lo = min((int)blockIdx.x * per_wg, B), hi = min(lo + per_wg, B);
-  for (int c = tid; c < ncell; c += 1024) hist[c] = 0;
-  __syncthreads();
-  int kk[PER_T];
-#pragma unroll
-  for (int i = 0; i < PER_T; ++i) {
-    const int b = tid + 1024 * i;
-    const int bc = min(b, B - 1);
-    const int64_t r = idx ? idx[bc] : bc;
-    kk[i] = cell_of(coords[2 * r], coords[2 * r + 1], G);       // unconditional, clamped
-  }
-#pragma unroll
-  for (int i = 0; i < PER_T; ++i) {
-    const int b = tid + 1024 * i;
-    if (b < B) {
-      if (b >= lo && b < hi) keys[b] = kk[i];
-      atomicAdd(&hist[kk[i]], 1);
-    }
-  }
-  __syncthreads();
-  // exclusive scan: thread tid owns cells [tid*per, tid*per+per); wave-level shuffles, two barriers
-  const int per = (ncell + 1023) / 1024;
-  const int i0 = tid * per, i1 = min(i0 + per, ncell);
-  int s = 0;
-  for (int i = i0; i < i1; ++i) s += hist[i];
-  const int lane = tid & 63, wv = tid >> 6;
-  int incl = s;                                  // inclusive scan inside the wave
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
-  if (lane == 63) part[wv] = incl;               // wave totals
-  __syncthreads();
-  if (tid < 16) {                                // 16 waves: scan their totals in one wave
-    int tot = part[tid];
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      const int v = __shfl_up(tot, o, 64);
-      if (tid >= o) tot += v;
-    }
-    part[16 + tid] = tot;                        // inclusive totals
-  }
-  __syncthreads();
-  int run = incl - s + (wv > 0 ? part[16 + wv - 1] : 0);
-  for (int i = i0; i < i1; ++i) {
-    const int cnt = hist[i];
-    start[i] = run;
-    if (blockIdx.x == 0) cell_start[i] = run;
-    hist[i] = run;            // cursor for the scatter
-    run += cnt;
-  }
-  if (tid == 1023) {
-    start[ncell] = part[31];
-    if (blockIdx.x == 0) cell_start[ncell] = part[31];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < PER_T; ++i) {
-    const int b = tid + 1024 * i;
-    if (b < B) ptmp[atomicAdd(&hist[kk[i]], 1)] = b;
-  }
-  __syncthreads();
-  // order every cell that reaches into [lo, hi) by original index (rank by counting): LDS only
-  for (int c = tid; c < ncell; c += 1024) {
-    const int s0 = start[c], s1 = start[c + 1];
-    if (s1 <= lo || s0 >= hi) continue;
-    for (int i = s0; i < s1; ++i) {
-      const int b = ptmp[i];
-      int rank = 0;
-      for (int j = s0; j < s1; ++j) rank += ptmp[j] < b;
-      pfin[s0 + rank] = b;
-    }
-  }
-  __syncthreads();
-  // emit the sorted arrays: one position per thread and pass, independent loads
-#pragma unroll
-  for (int i = 0; i < PER_T; ++i) {
-    const int pos = lo + tid + 1024 * i;
-    if (lo + 1024 * i >= hi) break;              // workgroup-uniform
-    const int b = pfin[min(pos, hi - 1)];
-    const int64_t r = idx ? idx[b] : b;
-    const float cx = coords[2 * r], cy = coords[2 * r + 1];
-    const float tv = t ? t[r] : 0.f;
-    if (pos < hi) {
-      perm[pos] = b;
-      xs[pos] = cx;
-      ys[pos] = cy;
-      if (t) ts[pos] = tv;
-      if (y_s)
-        for (int q = 0; q < Q; ++q) y_s[(int64_t)pos * Q + q] = y[r * Q + q];
-      if (X_s)
-        for (int q = 0; q < p; ++q) X_s[(int64_t)pos * p + q] = X[r * p + q];
-    }
-  }
+__global__ __launch_bounds__(1024) void bin_small_kernel(BinSmallArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int bin_smem[];
+  bin_small_body(a, (int)blockIdx.x, (int)gridDim.x, bin_smem);
 }
+
+BinSmallArgs bin_small_args(const float *coords, const float *t, const float *y, int Q, const float *X, int p, int B,
+                            int G, const BinBuffers &bb, const int64_t *idx) {
+  BinSmallArgs a;
+  a.idx = idx; a.coords = coords; a.t = t; a.y = y; a.X = X; a.Q = Q; a.p = p; a.B = B; a.G = G;
+  a.keys = bb.keys; a.cell_start = bb.cell_start; a.perm = bb.perm;
+  a.xs = bb.xs; a.ys = bb.ys; a.ts = bb.ts;
+  a.y_s = y ? bb.y_s : nullptr;
+  a.X_s = (X && p > 0) ? bb.X_s : nullptr;
+  return a;
+}
+bool bin_small_eligible(int B, int G) { return B <= SMALL_B && G <= SMALL_G; }
 
 int bin_obs(const float *coords, const float *t, const float *y, int Q, const float *X, int p, int B,
             int G, const BinBuffers &bb, hipStream_t st, const int64_t *idx, bool many_small) {
   const int ncell = G * G;
   if (B <= SMALL_B && G <= SMALL_G && !many_small) {
     // (a few hundred rows are not worth splitting: one workgroup)
-    STDADK_LAUNCH(bin_small_kernel, dim3(B >= 1024 ? SMALL_WG : 1), dim3(1024), 0, st, idx, coords, t, y, Q, X, p, B, G, bb.keys,
-                  bb.cell_start, bb.perm, bb.xs, bb.ys, bb.ts, y ? bb.y_s : (float *)nullptr,
-                  (X && p > 0) ? bb.X_s : (float *)nullptr);
+    BinSmallArgs ba = bin_small_args(coords, t, y, Q, X, p, B, G, bb, idx);
+    static bool attr = false;       // > 64 KiB of dynamic LDS: raised on the first (eager) call
+    if (!attr) {
+      hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void *>(bin_small_kernel), BIN_SMALL_LDS_INTS * (int)sizeof(int));
+      if (e != hipSuccess) { set_error("bin_obs: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+      attr = true;
+    }
+    STDADK_LAUNCH(bin_small_kernel, dim3(B >= 1024 ? SMALL_WG : 1), dim3(1024), BIN_SMALL_LDS_INTS * sizeof(int), st, ba);
     STDADK_CHECK_LAUNCH("bin_obs");
     return 0;
   }

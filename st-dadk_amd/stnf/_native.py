@@ -48,7 +48,7 @@ class BasisDesc(C.Structure):
                 ("t_bw", C.c_void_p)]
 
 
-ABI_VERSION = 7            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
+ABI_VERSION = 8            # STDADK_ABI_VERSION of include/stdadk.h this binding was written against
 MAX_Q = 8
 LOSS_MSE, LOSS_PINBALL = 0, 1
 
@@ -140,6 +140,12 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_int64, C.c_float, C.POINTER(LossDesc),
                                         C.POINTER(SparsityDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
                                         C.c_int32, C.POINTER(OptimDesc), C.c_void_p]),
+    "stdadk_train_step_next_f32": (C.c_int, [C.POINTER(BasisDesc), C.POINTER(MlpDesc), C.POINTER(MlpTensors),
+                                             C.POINTER(MlpTensors), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int64, C.c_float, C.POINTER(LossDesc),
+                                             C.POINTER(SparsityDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
+                                             C.c_int32, C.POINTER(OptimDesc), C.c_void_p, C.c_int64, C.c_int32,
+                                             C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_void_p]),
     "stdadk_sumsq2_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "stdadk_adamw_ema2_f32": (C.c_int, [C.POINTER(AdamGroup), C.POINTER(AdamGroup), C.c_float, C.c_float,
@@ -760,6 +766,29 @@ def train_step(basis, desc, params, grads, coords, t, X, y, idx, B, grad_scale, 
         C.byref(sparsity_desc) if sparsity_desc is not None else None, _dev(loss_sum, "loss_sum"), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), seed, flags, C.byref(optim), _stream())
     _check(rc, "stdadk_train_step_f32")
+
+
+def train_step_next(basis, desc, params, grads, coords_all, t_all, X_all, y_all, idx, grad_scale, loss_sum, workspace,
+                    flags, optim, next_idx, next_workspace, seed=0, loss_desc=None, sparsity_desc=None):
+    """train_step on rows `idx` of the resident arrays whose optimiser launch also bins rows `next_idx` into
+    `next_workspace` (stdadk_train_step_next_f32).  Returns True when the next batch was binned (step on
+    next_workspace with FLAG_PREBINNED then), False when nothing was prepared."""
+    for nm, ix in (("idx", idx), ("next_idx", next_idx)):
+        if ix.dtype != torch.int64 or not _on_device(ix) or not ix.is_contiguous():
+            raise RuntimeError(f"train_step_next: {nm} must be a contiguous int64 tensor on the device")
+    if next_workspace.data_ptr() == workspace.data_ptr():
+        raise RuntimeError("train_step_next: the next batch needs a workspace of its own")
+    done = C.c_int32(0)
+    rc = lib().stdadk_train_step_next_f32(
+        C.byref(basis), C.byref(desc), C.byref(params), C.byref(grads), _dev(coords_all, "coords"), _dev(t_all, "t"),
+        _dev(X_all, "X"), _dev(y_all, "y"), idx.data_ptr(), idx.numel(), grad_scale,
+        C.byref(loss_desc) if loss_desc is not None else None,
+        C.byref(sparsity_desc) if sparsity_desc is not None else None, _dev(loss_sum, "loss_sum"), workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), seed, flags, C.byref(optim), next_idx.data_ptr(), next_idx.numel(),
+        y_all.shape[1] if y_all is not None else 0, next_workspace.data_ptr(),
+        next_workspace.numel() * next_workspace.element_size(), C.byref(done), _stream())
+    _check(rc, "stdadk_train_step_next_f32")
+    return bool(done.value)
 
 
 def sumsq2(g0, parts0, g1, parts1, step_inc=None):

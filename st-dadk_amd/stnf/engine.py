@@ -15,6 +15,8 @@ runs the same arithmetic as one chain of HIP kernels on one stream with
 import math
 import weakref
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -157,7 +159,7 @@ class TrainStep:
                  domain_penalty_weight=0.0, movement_penalty_weight=0.0, sparsity_penalty_type="none",
                  sparsity_lambda_l1=0.001, sparsity_lambda_group=0.01, sparsity_apply_to_spatial=True,
                  sparsity_apply_to_temporal=True, seed=None, world_size=None, dtype="f32", shard_optimizer=False,
-                 sync_init=True, nonfinite_guard=True):
+                 sync_init=True, nonfinite_guard=True, inline_prep=True):
         self.model = model
         if dtype not in ("f32", "bf16"):
             raise ValueError(f"unknown dtype '{dtype}'; use 'f32' or 'bf16'")
@@ -320,7 +322,10 @@ class TrainStep:
         self._optim = None
         self._sumsq512 = torch.zeros(N.GRADSQ_PARTS, device=self.dev)
         self._pipe = None          # two workspaces + side stream of the pipelined batch preparation
-        self._prepared = None      # ((idx data_ptr, numel), workspace index, idx tensor) of the announced batch
+        self._prepared = None      # ((idx data_ptr, numel, stride), workspace index, idx tensor, inline) of the announced batch
+        # small batches of the one-call step: the next batch is binned inside this step's optimiser launch
+        # (False or STNF_NO_INLINE_PREP=1: on the side stream, as for every other step kind)
+        self.inline_prep = bool(inline_prep) and os.environ.get("STNF_NO_INLINE_PREP", "") != "1"
         self.time_allreduce = False   # bench: bracket the step's collectives with timing events
         self.allreduce_events = []
         # clip-norm partials of both parameter groups in ONE buffer (the sharded optimiser all-reduces it once)
@@ -393,10 +398,12 @@ class TrainStep:
         self.basis_lr = float(lr)
         self.basis_lr_dev.fill_(self.basis_lr)
 
-    def _enqueue(self, X, coords, t, y, B, global_rows, idx=None, ws=None, prebinned=False):
+    def _enqueue(self, X, coords, t, y, B, global_rows, idx=None, ws=None, prebinned=False, nxt=None):
         """All kernels of one step on the current stream (capturable: no sync, no allocation).
         With `idx` (window path) X/coords/t/y are the RESIDENT arrays and the batch is their rows idx;
-        `prebinned`: the batch already sits binned in workspace `ws` (pipelined preparation)."""
+        `prebinned`: the batch already sits binned in workspace `ws` (pipelined preparation).
+        `nxt` = (next_idx, next_workspace), one-call step only: the optimiser launch also bins the next batch
+        (stdadk_train_step_next_f32); returns True when it did."""
         st = self.state
         ws = self.ws if ws is None else ws
         flags = st.flags | (N.FLAG_PREBINNED if prebinned else 0)
@@ -409,11 +416,16 @@ class TrainStep:
                                            self.betas, self.eps, self.wd, self.step_dev, self.grad_clip,
                                            self._sumsq512 if self.grad_clip > 0 else None, self.ema_decay,
                                            shadow=self._shadow(0), nonfinite_step=self.nonfinite)
+            if nxt is not None:
+                return N.train_step_next(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y, idx,
+                                         D.grad_scale(global_rows, Q), self.loss_sum, ws, flags, self._optim, nxt[0],
+                                         nxt[1], seed=self.seed, loss_desc=self._loss_desc(y.shape[1]),
+                                         sparsity_desc=self._sparsity)
             N.train_step(st.basis, st.desc, st.params, self.grads_t, coords, t, X, y,
                          idx if not prebinned else None, B, D.grad_scale(global_rows, Q), self.loss_sum, ws, flags,
                          self._optim, seed=self.seed, loss_desc=self._loss_desc(y.shape[1]),
                          sparsity_desc=self._sparsity)
-            return
+            return False
         self._enqueue_grads(X, coords, t, y, B, global_rows, idx=idx, ws=ws, prebinned=prebinned)
         if self.shard:
             if not self.distributed:
@@ -798,12 +810,38 @@ class TrainStep:
             key = (idx.data_ptr(), idx.numel(), idx.stride(0) if idx.dim() else 1)
         if prep is not None and prep[0] == key:
             wsi, prebinned = prep[1], True
-            _wait(main, pp["binned"])
+            if not prep[3]:
+                _wait(main, pp["binned"])       # (prepared inside the previous step's optimiser launch: same stream)
         else:
             wsi, prebinned = 1 - pp["last"], False        # not announced: bin inside the step, in place
-            if prep is not None:
+            if prep is not None and not prep[3]:
                 # another batch was announced: the side stream may still be binning it into exactly this workspace
                 _wait(main, pp["binned"])
+        # one-call step on a small batch: the NEXT batch is binned by extra workgroups of this step's optimiser launch
+        # (no side stream, no cross-stream packets in the main queue: DESIGN.md section 8, "the bubble between steps")
+        inline = (next_idx is not None and self._whole_step and self.inline_prep and not self.distributed
+                  and next_idx.numel() <= 8192 and next_idx.dtype == torch.int64)
+        if inline:
+            nxt = next_idx if next_idx.is_contiguous() else next_idx.contiguous()
+            wsj = 1 - wsi
+            me = idx if idx.is_contiguous() else idx.contiguous()
+            done = self._enqueue(Xa, coords_all, t_all, y_all, B, global_rows, idx=me, ws=pp["ws"][wsi],
+                                 prebinned=prebinned, nxt=(nxt, pp["ws"][wsj]))
+            if done:
+                self._prepared = ((next_idx.data_ptr(), next_idx.numel(), next_idx.stride(0) if next_idx.dim() else 1),
+                                  wsj, nxt, True)
+                pp["last"] = wsi
+                return
+            # (the library did not take it -- e.g. more than 64 x 64 cells: the step itself is done, prepare as usual)
+            pp["announce"].record(main)
+            _wait(pp["stream"], pp["announce"])
+            with torch.cuda.stream(pp["stream"]):
+                N.bin_batch(st.basis, st.desc, coords_all, t_all, Xa, y_all, nxt, pp["ws"][wsj], st.flags)
+                pp["binned"].record(pp["stream"])
+            self._prepared = ((next_idx.data_ptr(), next_idx.numel(), next_idx.stride(0) if next_idx.dim() else 1),
+                              wsj, nxt, False)
+            pp["last"] = wsi
+            return
         if next_idx is not None:
             nxt = next_idx if next_idx.is_contiguous() else next_idx.contiguous()
             # the side stream starts after everything enqueued on the main stream so far: the step that last
@@ -824,7 +862,7 @@ class TrainStep:
                 N.bin_batch(st.basis, st.desc, coords_all, t_all, Xa, y_all, nxt, pp["ws"][wsj], st.flags)
                 pp["binned"].record(pp["stream"])
             self._prepared = ((next_idx.data_ptr(), next_idx.numel(), next_idx.stride(0) if next_idx.dim() else 1),
-                              wsj, nxt)
+                              wsj, nxt, False)
         pp["last"] = wsi
 
     def _step_graph(self, X, coords, t, y, B, global_rows):

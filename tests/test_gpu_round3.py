@@ -476,3 +476,34 @@ def test_large_batch_steps_are_reproducible_run_to_run(dropout):
     assert torch.isfinite(res[0][0]).all()
     assert torch.equal(res[0][0], res[1][0])
     assert abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[0][1])
+
+
+@pytest.mark.parametrize("name,B,dtype", [("c2_b257", 4096, "f32"), ("c2_b257", 1500, "f32"), ("default227", 700, "f32"),
+                                           ("c2_b257", 4096, "bf16")])
+def test_next_batch_binned_inside_the_optimiser_launch(name, B, dtype):
+    """One-call steps on small batches bin the NEXT batch with extra workgroups of their optimiser launch
+    (stdadk_train_step_next_f32, adamw_bin_kernel) instead of on a side stream: the binning is the same integer
+    work (bit-identical bins) and the optimiser's arithmetic does not depend on the launch shape, so a run of steps
+    ends in bit-identical parameters either way; the loss sums (float atomics) agree to rounding."""
+    from stnf.engine import TrainStep
+    cfg = dict(cases.MODEL_CASES[name], B=4 * B + 37, seed=21)
+    d = dev()
+    X, coords, t, y = (torch.from_numpy(a).to(d) if a is not None else None for a in cases.make_inputs(cfg))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    perm = torch.randperm(coords.shape[0], generator=g).to(d)
+    batches = [perm[i * B:(i + 1) * B] for i in range(4)] + [perm[:B // 2]]        # the last one ragged
+    res = []
+    for inline in (True, False):
+        m = T.build_model(cfg, dropout=0.1).train()
+        eng = TrainStep(m, lr=1e-3, grad_clip=0.5, max_batch=B, dtype=dtype, seed=11, inline_prep=inline)
+        assert eng._whole_step
+        for i, idx in enumerate(batches):
+            eng.step_indexed(coords, t.view(-1), y, idx, next_idx=batches[i + 1] if i + 1 < len(batches) else None)
+            if i == 1:
+                assert eng._prepared is not None and eng._prepared[3] == inline
+        torch.cuda.synchronize()
+        res.append((eng.flat.clone(), eng.mean_loss(), int(eng.step_dev.item())))
+    assert res[0][2] == res[1][2] == len(batches)
+    assert torch.isfinite(res[0][0]).all()
+    assert torch.equal(res[0][0], res[1][0])
+    assert abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[0][1])

@@ -43,6 +43,11 @@ def steps(m, B, eng_kw=None, q_cols=1, indexed=True):
     if indexed and m.p == 0:
         idx = torch.arange(B - 1, -1, -1)
         eng.step_indexed(c, t, y, idx)
+        if eng._whole_step and eng.uses_window:
+            # the step whose optimiser launch also bins the next batch (stdadk_train_step_next_f32): planning of both
+            eng._enqueue(None, c, t.view(-1), y, B, B, idx=idx, ws=eng.ws,
+                         nxt=(idx[: max(B // 2, 1)].contiguous(), torch.empty_like(eng.ws)))
+            calls += 1
     calls += 3
     if eng.ema is not None:
         eng.swap_in_ema(); eng.swap_in_ema()
