@@ -479,7 +479,7 @@ def test_large_batch_steps_are_reproducible_run_to_run(dropout):
 
 
 @pytest.mark.parametrize("name,B,dtype", [("c2_b257", 4096, "f32"), ("c2_b257", 1500, "f32"), ("default227", 700, "f32"),
-                                           ("c2_b257", 4096, "bf16")])
+                                           ("c2_b257", 4096, "bf16"), ("c2_b257", 6000, "f32")])
 def test_next_batch_binned_inside_the_optimiser_launch(name, B, dtype):
     """One-call steps on small batches bin the NEXT batch with extra workgroups of their optimiser launch
     (stdadk_train_step_next_f32, adamw_bin_kernel) instead of on a side stream: the binning is the same integer
@@ -500,7 +500,8 @@ def test_next_batch_binned_inside_the_optimiser_launch(name, B, dtype):
         for i, idx in enumerate(batches):
             eng.step_indexed(coords, t.view(-1), y, idx, next_idx=batches[i + 1] if i + 1 < len(batches) else None)
             if i == 1:
-                assert eng._prepared is not None and eng._prepared[3] == inline
+                # (6 000 rows take a 128 x 128 cell grid: the library declines, the engine prepares on the side stream)
+                assert eng._prepared is not None and eng._prepared[3] == (inline and B <= 4096)
         torch.cuda.synchronize()
         res.append((eng.flat.clone(), eng.mean_loss(), int(eng.step_dev.item())))
     assert res[0][2] == res[1][2] == len(batches)
