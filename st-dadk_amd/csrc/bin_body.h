@@ -12,8 +12,15 @@ constexpr int SMALL_B = 8192, SMALL_G = 64, SMALL_WG = 8;
 // dynamic LDS of a binning workgroup for a batch of B rows, in ints: counters + scan of the cells, the two permutations
 // (sized by the batch: 68 KiB at 4 096 rows -- two workgroups per CU -- 100 KiB at 8 192), 1024 scan partials
 __host__ __device__ constexpr int bin_small_cap(int B) { return (B + 1023) & ~1023; }
-__host__ __device__ constexpr int bin_small_lds_ints(int B) { return 2 * SMALL_G * SMALL_G + 4 + 2 * bin_small_cap(B) + 1024; }
-constexpr int BIN_SMALL_LDS_INTS = 2 * SMALL_G * SMALL_G + 4 + 2 * SMALL_B + 1024;      // the most (B = SMALL_B)
+// up to 4 096 rows the row numbers idx[b] are kept in LDS too (int64: + 32 KiB), so that the emission does not fetch
+// them again behind the sort -- one dependent global round trip less, which counts when the binning runs beside the
+// optimiser's HBM stream (adamw_bin_kernel)
+__host__ __device__ constexpr bool bin_small_stages_rows(int B) { return bin_small_cap(B) <= 4096; }
+__host__ __device__ constexpr int bin_small_lds_ints(int B) {
+  return 2 * SMALL_G * SMALL_G + 4 + 2 * bin_small_cap(B) + 1024 + (bin_small_stages_rows(B) ? 2 * bin_small_cap(B) : 0);
+}
+constexpr int BIN_SMALL_LDS_INTS = 2 * SMALL_G * SMALL_G + 4 + 2 * SMALL_B + 1024;      // the most (B = SMALL_B: 100 KiB)
+static_assert(bin_small_lds_ints(4096) <= BIN_SMALL_LDS_INTS, "the staged row numbers must fit the largest image");
 
 struct BinSmallArgs {
   const int64_t *idx;               // rows of the resident arrays, or NULL (rows 0..B-1)
@@ -36,6 +43,8 @@ __device__ __forceinline__ void bin_small_body(const BinSmallArgs &a, const int 
   int *ptmp = start + SMALL_G * SMALL_G + 4;          // [cap(B)] unordered permutation
   int *pfin = ptmp + bin_small_cap(a.B);              // [cap(B)] ordered permutation
   int *part = pfin + bin_small_cap(a.B);              // [1024]
+  const bool stage = bin_small_stages_rows(a.B) && a.idx != nullptr;
+  long long *rows = reinterpret_cast<long long *>(part + 1024);   // [cap(B)] idx[b], when staged
   const int64_t *__restrict__ idx = a.idx;
   const float *__restrict__ coords = a.coords, *__restrict__ t = a.t, *__restrict__ y = a.y, *__restrict__ X = a.X;
   const int Q = a.Q, p = a.p, B = a.B, G = a.G;
@@ -56,6 +65,7 @@ __device__ __forceinline__ void bin_small_body(const BinSmallArgs &a, const int 
     const int b = tid + 1024 * i;
     const int bc = min(b, B - 1);
     const int64_t r = idx ? idx[bc] : bc;
+    if (stage && b < B) rows[b] = r;
     kk[i] = bin_cell_of(coords[2 * r], coords[2 * r + 1], G);       // unconditional, clamped
   }
 #pragma unroll
@@ -128,7 +138,7 @@ __device__ __forceinline__ void bin_small_body(const BinSmallArgs &a, const int 
     const int pos = lo + tid + 1024 * i;
     if (lo + 1024 * i >= hi) break;              // workgroup-uniform
     const int b = pfin[min(pos, hi - 1)];
-    const int64_t r = idx ? idx[b] : b;
+    const int64_t r = stage ? (int64_t)rows[b] : (idx ? idx[b] : b);
     const float cx = coords[2 * r], cy = coords[2 * r + 1];
     const float tv = t ? t[r] : 0.f;
     if (pos < hi) {

@@ -139,12 +139,16 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
   if (has_ema) ema = fmaf(ema_decay, ema, (1.f - ema_decay) * p);
 }
 
-__device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int block, const int nblocks) {
+// `block` of `nblocks` groups of 256 threads; `tid` = the thread's index in its group, `red4` = four floats of LDS of
+// the group (a group is a whole workgroup in adamw_ema_kernel, a quarter of one in adamw_bin_kernel: the barrier in
+// the middle is the workgroup's, which every group of the workgroup reaches)
+__device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int block, const int nblocks, const int tid,
+                                                float *red4) {
   // The first (for up to 4 M parameters: the only) float4 group of every stream is requested BEFORE the
   // prologue below (partials of the clip norm, bias corrections), whose latency then hides behind it.
   typedef float nt4 __attribute__((ext_vector_type(4)));
-  const int64_t stride = (int64_t)nblocks * blockDim.x;
-  const int64_t i0 = (int64_t)block * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)nblocks * 256;
+  const int64_t i0 = (int64_t)block * 256 + tid;
   const bool al = ((reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(a.g) |
                     reinterpret_cast<uintptr_t>(a.m) | reinterpret_cast<uintptr_t>(a.v) |
                     reinterpret_cast<uintptr_t>(a.ema)) & 15) == 0;
@@ -164,23 +168,19 @@ __device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int blo
   // non-finite guard: the objective accumulator is a running sum, so the first step that leaves it non-finite is the
   // first step whose batch objective was (scripts/train_st_interp.py:724-733 stops the epoch there); one thread of
   // the launch, launches of a stream run in order: no atomics
-  if (a.bad_step && block == 0 && threadIdx.x == 0) {
+  if (a.bad_step && block == 0 && tid == 0) {
     const float l = a.watch[0];
     if (!(fabsf(l) <= 3.402823466e38f) && a.bad_step[0] == 0) a.bad_step[0] = step;
   }
   float coef = 1.f;
   if (a.max_norm > 0.f && a.sumsq) {
-    // block-wide sum of the partials, same order in every block (L2-resident, a few hundred floats): by the first
-    // 256 threads whatever the block size, so that the value does not depend on the launch shape
-    __shared__ float red[4];
+    // sum of the partials by the group's 256 threads, same order in every group (L2-resident, a few hundred floats)
     float ss = 0.f;
-    if (threadIdx.x < 256) {
-      for (int i = threadIdx.x; i < a.n_parts; i += 256) ss += a.sumsq[i];
-      ss = wave_sum(ss);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    }
+    for (int i = tid; i < a.n_parts; i += 256) ss += a.sumsq[i];
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red4[tid >> 6] = ss;
     __syncthreads();
-    ss = (red[0] + red[1]) + (red[2] + red[3]);
+    ss = (red4[0] + red4[1]) + (red4[2] + red4[3]);
     coef = fminf(1.f, a.max_norm / (sqrtf(ss) + 1e-6f));
   }
   const float gm = coef * a.grad_mul;
@@ -236,14 +236,16 @@ __device__ __forceinline__ void adamw_ema_block(const AdamArgs &a, const int blo
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
-  adamw_ema_block(a, (int)blockIdx.x, (int)gridDim.x);
+  __shared__ float red[4];
+  adamw_ema_block(a, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, red);
 }
 
 // two parameter groups (own lr, clip norm and clip partials each) in one launch: blocks [0, nb0) update
 // group 0, the rest group 1
 __global__ __launch_bounds__(256) void adamw_ema2_kernel(AdamArgs a0, AdamArgs a1, int nb0) {
-  if ((int)blockIdx.x < nb0) adamw_ema_block(a0, (int)blockIdx.x, nb0);
-  else adamw_ema_block(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+  __shared__ float red[4];
+  if ((int)blockIdx.x < nb0) adamw_ema_block(a0, (int)blockIdx.x, nb0, (int)threadIdx.x, red);
+  else adamw_ema_block(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, (int)threadIdx.x, red);
 }
 
 // The optimiser launch of a step that also bins the NEXT batch (bin_body.h): workgroups [0, n_bin) are the
@@ -254,8 +256,11 @@ __global__ __launch_bounds__(256) void adamw_ema2_kernel(AdamArgs a0, AdamArgs a
 // path, no side stream and none of its cross-stream packets (profiles/r03_step_timeline.txt: 6-7 us per step).
 __global__ __launch_bounds__(1024) void adamw_bin_kernel(AdamArgs a, BinSmallArgs b, int n_bin) {
   extern __shared__ __attribute__((aligned(16))) int bin_smem[];
+  __shared__ float red[4][4];
   if ((int)blockIdx.x < n_bin) { bin_small_body(b, (int)blockIdx.x, n_bin, bin_smem); return; }
-  adamw_ema_block(a, (int)blockIdx.x - n_bin, (int)gridDim.x - n_bin);
+  // four groups of 256 threads per workgroup: the access pattern of adamw_ema_kernel with four times the blocks
+  const int grp = (int)threadIdx.x >> 8;
+  adamw_ema_block(a, 4 * ((int)blockIdx.x - n_bin) + grp, 4 * ((int)gridDim.x - n_bin), (int)threadIdx.x & 255, red[grp]);
 }
 
 __global__ void step_advance_kernel(int *s) { s[0] += 1; }
@@ -322,10 +327,11 @@ static int adamw_impl(float *p, const float *g, float *m, float *v, float *ema, 
   if (bin) {
     // one resident round of 1024-thread workgroups (the dynamic LDS of the binning allows one per CU): the binning
     // workgroups first, the optimiser on the other CUs
-    const int n_bin = bin->B >= 1024 ? SMALL_WG : 1;
+    int n_bin = bin->B >= 1024 ? SMALL_WG : 1;
+    { const char *e = getenv("STDADK_BIN_WG"); if (e && atoi(e) > 0 && bin->B >= 1024) n_bin = atoi(e); }   // measurement aid
     const size_t lds = (size_t)bin_small_lds_ints(bin->B) * sizeof(int);
     const int per_cu = lds <= 78 * 1024 ? 2 : 1;               // workgroups of this launch a CU holds (160 KiB of LDS)
-    int64_t ab = ceil_div(n, 1024 * 4);
+    int64_t ab = (blocks + 3) / 4;                                // the same groups of 256 threads as the plain launch
     if (ab > 256 * per_cu - n_bin) ab = 256 * per_cu - n_bin;
     static bool attr = false;
     if (!attr) {
