@@ -1,9 +1,9 @@
 #!/bin/bash
 set -uo pipefail
 cd "$(dirname "$0")/.."
-bash tools/profile_round.sh r03 598bd23 > gpurun_out/r03_profile.log 2>&1 || { tail -5 gpurun_out/r03_profile.log; exit 1; }
-bash tools/profile_round.sh r03_b65536 598bd23 --batch 65536 > gpurun_out/r03_b65536_profile.log 2>&1 || { tail -5 gpurun_out/r03_b65536_profile.log; exit 1; }
-bash tools/profile_round.sh r03_bf16 598bd23 --dtype bf16 > gpurun_out/r03_bf16_profile.log 2>&1 || { tail -5 gpurun_out/r03_bf16_profile.log; exit 1; }
+bash tools/profile_round.sh r03 bed3ddb > gpurun_out/r03_profile.log 2>&1 || { tail -5 gpurun_out/r03_profile.log; exit 1; }
+bash tools/profile_round.sh r03_b65536 bed3ddb --batch 65536 > gpurun_out/r03_b65536_profile.log 2>&1 || { tail -5 gpurun_out/r03_b65536_profile.log; exit 1; }
+bash tools/profile_round.sh r03_bf16 bed3ddb --dtype bf16 > gpurun_out/r03_bf16_profile.log 2>&1 || { tail -5 gpurun_out/r03_bf16_profile.log; exit 1; }
 mkdir -p gpurun_out/r3v
 python bench.py > gpurun_out/r3v/bench_default.json 2> gpurun_out/r3v/bench_default.err; echo "default rc=$?"
 python bench.py --steps 200 --warmup 20 --no-sweep > gpurun_out/r3v/bench_driver_args.json 2> gpurun_out/r3v/bench_driver_args.err; echo "driver rc=$?"
