@@ -501,7 +501,8 @@ def test_next_batch_binned_inside_the_optimiser_launch(name, B, dtype):
             eng.step_indexed(coords, t.view(-1), y, idx, next_idx=batches[i + 1] if i + 1 < len(batches) else None)
             if i == 1:
                 # (6 000 rows take a 128 x 128 cell grid: the library declines, the engine prepares on the side stream)
-                assert eng._prepared is not None and eng._prepared[3] == (inline and B <= 4096)
+                # (STNF_NO_INLINE_PREP=1 in the environment switches it off for every engine)
+                assert eng._prepared is not None and eng._prepared[3] == (eng.inline_prep and B <= 4096)
         torch.cuda.synchronize()
         res.append((eng.flat.clone(), eng.mean_loss(), int(eng.step_dev.item())))
     assert res[0][2] == res[1][2] == len(batches)
